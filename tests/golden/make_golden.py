@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by EXECUTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are committed, the reference never travels.  Usage:
+
+    python3 -B tests/golden/make_golden.py
+
+How the reference is run: Numba is not installed here,
+so a stub module `numba` whose `njit(...)` is the identity decorator is placed
+in `sys.modules`; the reference's function bodies are plain NumPy and execute
+in float64.  `fastmath=True` only licenses re-association (~1e-15).  Nothing is
+written into /root/reference (`sys.dont_write_bytecode`).
+
+What each fixture holds: fp32-exact inputs (state, acceleration or previous
+velocity + dt, params, rho, g) and the reference's nine outputs per body
+(`solve_hydrodynamics`, numba_hydrodynamics.py:256-314) in float64.
+
+N1 completion: for a wet body with speed <= 1e-6 the reference's
+`calculate_pressure_and_area` returns None and `solve_hydrodynamics` raises
+(TypeError under plain Python).  For those bodies only, this script calls the
+reference's own sub-functions in the reference's order with
+`(center_of_pressure, area) = (center_of_buoyancy, 0.0)` substituted, and
+records the body in the fixture's `rest_completed` mask.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+REFERENCE_SCRIPTS = "/root/reference/src/scripts"
+
+
+def import_reference():
+    stub = types.ModuleType("numba")
+
+    def njit(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda fn: fn
+
+    stub.njit = njit
+    sys.modules["numba"] = stub
+    sys.path.insert(0, REFERENCE_SCRIPTS)
+    import physics.numba_hydrodynamics as ref_k                    # noqa: E402
+    import physics.numba_hydrodynamics_wrapper as ref_w            # noqa: E402
+    return ref_k, ref_w
+
+
+REF_K, REF_W = import_reference()
+
+
+def reference_body(state, accel, params, rho, g):
+    """Nine reference outputs for one body -> (array (8,3), ratio, rest_completed)."""
+    p, q, v, w = state[0:3], state[3:7], state[7:10], state[10:13]
+    a, al = accel[0:3], accel[3:6]
+    dims = [float(x) for x in params[0:3]]
+    cd_lin, cd_ang, damp_lin, damp_ang, lift_c, am_lin, am_ang = (float(x) for x in params[3:10])
+    wrap = REF_W.NumbaHydrodynamicsWrapper(
+        dims[0], dims[1], dims[2], cd_lin, cd_ang, damp_lin, damp_ang,
+        float(rho), float(g), am_lin, am_ang, lift_c)
+    try:
+        out = wrap.calculate_hydrodynamic_forces(p, q, v, w, a, al)
+        return np.stack([np.asarray(o, dtype=np.float64) for o in out[:8]]), float(out[8]), False
+    except TypeError:
+        pass
+    # ---- N1 completion, reference sub-functions in the reference's order ----
+    f64 = lambda x: np.asarray(x, dtype=np.float64)                # noqa: E731
+    p, q, v, w, a, al = map(f64, (p, q, v, w, a, al))
+    rot = REF_K.quaternion_to_matrix(q)
+    world = (rot @ wrap._local_keypoints.T).T + p
+    ratio, cob = REF_K.analyze_submersion_and_cob(world, p)
+    assert ratio > 1e-9, "TypeError is only expected on the wet rest branch"
+    buoy = np.array([0.0, 0.0, wrap.water_density * (ratio * wrap.total_volume) * wrap.gravity])
+    speed = np.linalg.norm(v)
+    assert not speed > 1e-6
+    vel_dir = np.zeros(3)
+    cop, area = cob, 0.0
+    drag_f, drag_t = REF_K.calculate_hybrid_drag(
+        speed, vel_dir, ratio, wrap.water_density, area, wrap.total_volume,
+        wrap.linear_drag_coefficient, wrap.linear_damping, v,
+        wrap.angular_drag_coefficient, wrap.angular_damping, w)
+    lift_f = REF_K.calculate_lift(speed, vel_dir, rot, area, wrap.water_density,
+                                  wrap.lift_coefficient, ratio)
+    am_f, am_t = REF_K.calculate_added_mass(ratio, a, al, rot, wrap._added_mass_matrix)
+    comps = np.stack([f64(x) for x in (buoy, drag_f, lift_f, drag_t, am_f, am_t, cob, cop)])
+    return comps, float(ratio), True
+
+
+def reference_batch(state, accel, params, rho, g):
+    n = state.shape[0]
+    comps = np.zeros((n, 8, 3))
+    ratio = np.zeros(n)
+    rest = np.zeros(n, dtype=bool)
+    for i in range(n):
+        comps[i], ratio[i], rest[i] = reference_body(state[i], accel[i], params[i], rho, g)
+    return comps, ratio, rest
+
+
+def accel_from_prev(scene):
+    """fp64 finite difference on the fp32-exact inputs (A13), what the fused path sees."""
+    return (scene.state[:, 7:13].astype(np.float64) - scene.prev.astype(np.float64)) / np.float64(scene.dt)
+
+
+def save_scene_fixture(name, scene, idx):
+    state, prev, params = scene.state[idx], scene.prev[idx], scene.params[idx]
+    accel = accel_from_prev(scene)[idx]
+    comps, ratio, rest = reference_batch(state, accel, params, scene.rho, scene.g)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, index=np.asarray(idx, dtype=np.int64), state=state, prev=prev,
+                        params=params, rho=np.float64(scene.rho), g=np.float64(scene.g),
+                        dt=np.float64(scene.dt), components=comps, ratio=ratio, rest_completed=rest,
+                        scene_n=np.int64(scene.n))
+    print(f"{name}: {len(idx)} bodies of {scene.n}, rest-completed {int(rest.sum())}, "
+          f"dry {int((ratio == 0).sum())}, full {int((ratio == 1).sum())} -> {os.path.getsize(path)} B")
+
+
+def subsample(n, head, total):
+    """First `head` bodies plus an even stride through the rest, `total` indices."""
+    rest = np.linspace(head, n - 1, total - head).astype(np.int64)
+    return np.unique(np.concatenate([np.arange(head, dtype=np.int64), rest]))
+
+
+def known_answer_cases():
+    """K1-K5 of SURVEY.md section 8c (inputs as listed there)."""
+    std = (1.2, 0.8, 300.0, 150.0, 1.0, 0.05, 0.02)   # cd_lin cd_ang damp_lin damp_ang lift am_lin am_ang
+    def norm(q):
+        q = np.asarray(q, dtype=np.float64)
+        return q / np.linalg.norm(q)
+    cases = [
+        # name, dims, coeffs, p, q, v, w, a, alpha, mass
+        ("K1", (1, 1, 1), std, (0.1, 0.2, -0.2), norm((0.1, 0.2, 0.3, 0.9)), (0.3, -0.1, 0.5),
+         (0.2, 0.1, -0.4), (1, 2, 3), (-1, 0.5, 0.25), 500.0),
+        ("K2", (0.26, 0.26, 0.30), (1.2, 0.8, 300.0, 150.0, 0.5, 0.2, 0.1), (2.0, 10.7, -18.4415),
+         norm((0.05, -0.1, 0.7, 0.7)), (0.12, 0.03, -0.02), (0, 0.05, 0.3), (0.4, -0.2, 0.1), (0, 1, -2), 18.0),
+        ("K3", (0.06, 0.09, 0.06), (1.0, 0.1, 20.0, 2.0, 0.1, 0.0, 0.0), (1, -2, -19),
+         norm((0.3, 0.1, -0.2, 0.9)), (0.05, 0.02, -0.01), (0.01, -0.02, 0.05), (0.5, 0.5, 0.5), (1, 1, 1), 0.8),
+        ("K4", (1, 1, 3), std, (-7, 40, 0.596), norm((0.02, -0.03, 0, 1)), (3, 0.5, -4),
+         (0.1, 0.2, 0), (60, 0, -80), (0, 0, 0), 1.0),
+        ("K5", (1, 1, 1), std, (0, 0, 5), (0, 0, 0, 1), (1, 1, 1), (1, 1, 1), (0, 0, 0), (0, 0, 0), 1.0),
+    ]
+    names, state, accel, params = [], [], [], []
+    for name, dims, co, p, q, v, w, a, al, mass in cases:
+        names.append(name)
+        state.append(np.concatenate([p, q, v, w]).astype(np.float64))
+        accel.append(np.concatenate([a, al]).astype(np.float64))
+        params.append(np.concatenate([dims, co, [mass]]).astype(np.float64))
+    return names, np.stack(state), np.stack(accel), np.stack(params)
+
+
+def save_known_answers():
+    names, state, accel, params = known_answer_cases()
+    comps, ratio, rest = reference_batch(state, accel, params, 1025.0, 9.81)
+    path = os.path.join(HERE, "kat.npz")
+    np.savez_compressed(path, names=np.array(names), state=state, accel=accel, params=params,
+                        rho=np.float64(1025.0), g=np.float64(9.81), components=comps, ratio=ratio)
+    for n_, r_ in zip(names, ratio):
+        print(f"  {n_}: ratio {r_!r}")
+    print(f"kat: {len(names)} cases -> {os.path.getsize(path)} B")
+
+
+def save_c1_trajectory():
+    """Config 1: single buoy, 10 000 steps.  Forces from the reference functions;
+    epilogue (hydrodynamics_behavior.py:212-226 restated in fp64) and a semi-implicit
+    Euler point-mass integrator standing in for PhysX are this repo's own."""
+    from silver2_isaacsim_amd import scenes
+    from oracle import hydro_oracle as ho
+    sc = scenes.scene_c1()
+    steps = int(sc.info["steps"])
+    params = sc.params[0].astype(np.float64)
+    mass = params[10]
+    dt = np.float64(sc.dt)
+    p = sc.state[0, 0:3].astype(np.float64)
+    q = sc.state[0, 3:7].astype(np.float64)
+    v = sc.state[0, 7:10].astype(np.float64)
+    w = np.zeros(3)
+    v_last = np.zeros(3); w_last = np.zeros(3)
+    z_hist = np.zeros(steps); vz_hist = np.zeros(steps); fz_hist = np.zeros(steps)
+    rest_steps = []
+    for k in range(steps):
+        st = np.concatenate([p, q, v, w])
+        acc = np.concatenate([(v - v_last) / dt, (w - w_last) / dt])
+        comps, ratio, rest = reference_body(st, acc, params, sc.rho, sc.g)
+        if rest:
+            rest_steps.append(k)
+        net_f, _net_t, _ = ho.behavior_epilogue_one(p, list(comps), mass)
+        v_last = v.copy(); w_last = w.copy()
+        v = v + dt * (net_f / mass + np.array([0.0, 0.0, -sc.g]))
+        p = p + dt * v
+        z_hist[k], vz_hist[k], fz_hist[k] = p[2], v[2], net_f[2]
+    path = os.path.join(HERE, "c1_trajectory.npz")
+    np.savez_compressed(path, z=z_hist, vz=vz_hist, fz=fz_hist, rest_steps=np.array(rest_steps, dtype=np.int64),
+                        dt=dt, mass=np.float64(mass), params=params, rho=np.float64(sc.rho), g=np.float64(sc.g))
+    print(f"c1: {steps} steps, z in [{z_hist.min():.6f}, {z_hist.max():.6f}], final z {z_hist[-1]:.6f}, "
+          f"rest branch fired {len(rest_steps)}x -> {os.path.getsize(path)} B")
+
+
+def main():
+    from silver2_isaacsim_amd import scenes
+    save_known_answers()
+    sc = scenes.scene_c2()
+    save_scene_fixture("c2", sc, np.arange(sc.n))
+    sc = scenes.scene_c3()
+    save_scene_fixture("c3", sc, subsample(sc.n, 38, 1024))
+    sc = scenes.scene_c4()
+    save_scene_fixture("c4", sc, subsample(sc.n, 2048, 4096))
+    sc = scenes.scene_c5()
+    save_scene_fixture("c5", sc, subsample(sc.n, 1024, 2048))
+    sc = scenes.scene_c4(n=2048, seed=44, margin=None)
+    sc.name = "C4-adversarial"
+    save_scene_fixture("c4_adversarial", sc, np.arange(sc.n))
+    save_c1_trajectory()
+
+
+if __name__ == "__main__":
+    main()
