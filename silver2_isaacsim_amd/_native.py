@@ -1,0 +1,88 @@
+"""ctypes binding of libhydro.so (the C ABI declared in include/hydro.h).
+
+The shared library is built in-tree by `silver2_isaacsim_amd.build.build()`
+(`__graft_entry__.build()` calls it) into `silver2_isaacsim_amd/lib/`.  There is
+no CPU fallback: if the library is missing or fails to load, importing the
+binding raises, and every product entry point needs it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhydro.so")
+
+STATE_FIELDS, PREV_FIELDS, PARAM_FIELDS, WRENCH_FIELDS, COMP_FIELDS = 13, 6, 11, 6, 24
+
+HYDRO_OK = 0
+STATUS_NAMES = {0: "HYDRO_OK", -1: "HYDRO_E_ARG", -2: "HYDRO_E_ALLOC", -3: "HYDRO_E_LAUNCH",
+                -4: "HYDRO_E_DEVICE", -5: "HYDRO_E_STATE"}
+
+# every symbol include/hydro.h declares: (restype, argtypes)
+_FP = POINTER(c_void_p)      # table of field pointers (const float *const [N])
+SIGNATURES = {
+    "hydro_version": (c_int, []),
+    "hydro_status_string": (c_char_p, [c_int]),
+    "hydro_device_count": (c_int, [POINTER(c_int)]),
+    "hydro_create": (c_int, [c_int, c_int64, POINTER(c_void_p)]),
+    "hydro_destroy": (c_int, [c_void_p]),
+    "hydro_last_error": (c_char_p, [c_void_p]),
+    "hydro_capacity": (c_int64, [c_void_p]),
+    "hydro_set_scene": (c_int, [c_void_p, c_float, c_float]),
+    "hydro_set_params_f32": (c_int, [c_void_p, c_int64, _FP, c_int]),
+    "hydro_set_params_f16": (c_int, [c_void_p, c_int64, _FP, c_int]),
+    "hydro_reset_prev_velocity": (c_int, [c_void_p]),
+    "hydro_get_prev_velocity": (c_int, [c_void_p, c_int64, _FP, c_int]),
+    "hydro_set_prev_velocity": (c_int, [c_void_p, c_int64, _FP, c_int]),
+    "hydro_step_wrench": (c_int, [c_void_p, c_int64, _FP, c_float, _FP, c_void_p]),
+    "hydro_step_wrench_ext": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
+    "hydro_step_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
+                                      c_void_p, c_void_p, c_void_p]),
+    "hydro_step_components": (c_int, [c_void_p, c_int64, _FP, _FP, _FP, c_void_p, c_void_p]),
+    "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
+    "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
+    "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int]),
+    "hydro_sync": (c_int, [c_void_p]),
+    "hydro_stream": (c_void_p, [c_void_p]),
+}
+
+_lib = None
+
+
+class HydroError(RuntimeError):
+    """Non-zero status from libhydro.  A RuntimeError on purpose: the reference plugin's
+    state-fetch guard treats RuntimeError as "skip this step"
+    (hydrodynamics_behavior.py:191-192)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def load(path: str | None = None) -> ctypes.CDLL:
+    """Load libhydro.so and attach prototypes.  Raises OSError if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: the HIP extension is not built "
+                      f"(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def pointer_table(ptrs) -> ctypes.Array:
+    """ctypes array of raw addresses (ints) usable as `const float *const t[N]`."""
+    arr = (c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = int(p)
+    return arr

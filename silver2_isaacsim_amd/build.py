@@ -1,0 +1,49 @@
+"""In-tree build of libhydro.so for gfx950 (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "hydro_kernels.hip")
+DEPS = [SRC, os.path.join(_HERE, "csrc", "hydro_body.h"),
+        os.path.join(os.path.dirname(_HERE), "include", "hydro.h")]
+OUT = os.path.join(_HERE, "lib", "libhydro.so")
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found")
+    return p
+
+
+def is_stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    """Compile csrc/hydro_kernels.hip -> lib/libhydro.so.  Returns the library path."""
+    if not force and not is_stale():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc_path(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function"] + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode})")
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,303 @@
+// Per-body hydrodynamic wrench arithmetic for the gfx950 kernels.
+//
+// One call = one rigid body, one physics step.  fp32 throughout except the
+// vertical extent / submersion numerator, which is evaluated in fp64 because
+// `ratio = -z_min / (z_max - z_min)` cancels catastrophically for barely-wet
+// bodies (z_min = p_z - extent; SURVEY.md section 7 "hard parts").  No MFMA: the
+// path is elementwise per body.
+//
+// The model (what must come out) is the reference's
+//   numba_hydrodynamics.py:9-314      (A1-A11: rotation, submersion + CoB,
+//                                      CoP + projected area, hybrid drag, lift,
+//                                      added mass)
+//   hydrodynamics_behavior.py:196-226 (A13-A15: finite-difference acceleration,
+//                                      lever-arm torques, sum, 500 m/s^2 clamp)
+// The evaluation is restructured for the GPU (all closed forms checked against
+// the fp64 oracle, tests/test_numerics_host.py and tests/test_parity_gpu.py):
+//   * keypoint heights come from row 2 of R only:
+//       z_ijk = p_z + i*e_x + j*e_y + k*e_z,  e_a = h_a * R[2][a],  i,j,k in {-1,0,1}
+//     so z_min/max = p_z -/+ (|e_x|+|e_y|+|e_z|) and the 27 world points are
+//     never formed (numba_hydrodynamics.py:271 builds them with a 3x27 GEMM);
+//   * CoB and CoP are kept as BODY-RELATIVE lever arms (cob - p, cop - p):
+//     the wrench only ever uses those differences (hydrodynamics_behavior.py:
+//     212-214) and forming world-space points first loses ~|p|*2^-24 in fp32;
+//   * at most one face per axis opposes the flow, selected by sign(R^T v_hat);
+//   * sin(2*asin(d)) = 2 d sqrt((1-d)(1+d));  (axis x v_hat) = up|v_hat|^2 + d v_hat.
+// N1 completion (speed <= 1e-6 -> area 0, CoP = CoB) as in oracle/hydro_oracle.py.
+//
+// This header is compiled for the device by hipcc and, for the CPU-side
+// numerics study only (tests/host_emul), by the host compiler; the product
+// never calls the host instantiation.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define HYDRO_FN __host__ __device__ __forceinline__
+#else
+#define HYDRO_FN static inline __attribute__((always_inline))
+#endif
+
+namespace hydro {
+
+constexpr float kSpeedEps = 1e-6f;      // numba_hydrodynamics.py:118,156,170,192,286
+constexpr float kLowSpeed = 0.2f;       // :154
+constexpr float kInvLowSpeed = 5.0f;
+constexpr float kDryEps = 1e-9f;        // :192,225,277
+constexpr float kAreaEps = 1e-6f;       // :140
+constexpr float kHeightEps = 1e-6f;     // :92
+constexpr float kAxisEps = 1e-6f;       // :210
+constexpr float kMaxAccel = 500.0f;     // hydrodynamics_behavior.py:221
+constexpr float kClampEps = 1e-6f;      // hydrodynamics_behavior.py:224
+
+// Single-instruction transcendental forms on the device (v_sqrt_f32 / v_rcp_f32,
+// 1 ulp); plain libm on the host instantiation.
+HYDRO_FN float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+HYDRO_FN float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+struct BodyIn {
+    float px, py, pz;
+    float qx, qy, qz, qw;           // unit quaternion xyzw, NOT normalised (N7)
+    float vx, vy, vz;
+    float wx, wy, wz;
+    float ax, ay, az;               // linear acceleration
+    float bx, by, bz;               // angular acceleration
+    float dimx, dimy, dimz;
+    float cd_lin, cd_ang, damp_lin, damp_ang, lift, am_lin, am_ang;
+};
+
+struct BodyOut {
+    float ratio;                    // 0 when dry
+    float buoy_z;                   // buoyancy force is (0,0,buoy_z)
+    float drag_fx, drag_fy, drag_fz;
+    float lift_fx, lift_fy, lift_fz;
+    float drag_tx, drag_ty, drag_tz;
+    float am_fx, am_fy, am_fz;
+    float am_tx, am_ty, am_tz;
+    float armb_x, armb_y, armb_z;   // cob - p   (0 when dry)
+    float armp_x, armp_y, armp_z;   // cop - p   (0 when dry)
+    float dragarm_tx, dragarm_ty, dragarm_tz;   // (cop - p) x drag_force, cancellation-free form
+    bool wet;
+};
+
+// A1-A11.  rho, g are scene scalars (hydrodynamics_config.json:2-5 "globals").
+HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
+{
+    BodyOut o;
+
+    // ---- A1: rotation matrix, fp32 (numba_hydrodynamics.py:14-49) ----
+    const float x2 = b.qx + b.qx, y2 = b.qy + b.qy, z2 = b.qz + b.qz;
+    const float xx = b.qx * x2, xy = b.qx * y2, xz = b.qx * z2;
+    const float yy = b.qy * y2, yz = b.qy * z2, zz = b.qz * z2;
+    const float wx = b.qw * x2, wy = b.qw * y2, wz = b.qw * z2;
+    const float r00 = 1.0f - (yy + zz), r01 = xy - wz, r02 = xz + wy;
+    const float r10 = xy + wz, r11 = 1.0f - (xx + zz), r12 = yz - wx;
+
+    // ---- row 2 and the vertical extent in fp64 (conditioning, see header) ----
+    const double dqx = b.qx, dqy = b.qy, dqz = b.qz, dqw = b.qw;
+    const double d20 = 2.0 * (dqx * dqz - dqw * dqy);
+    const double d21 = 2.0 * (dqy * dqz + dqw * dqx);
+    const double d22 = 1.0 - 2.0 * (dqx * dqx + dqy * dqy);
+    const float hx = 0.5f * b.dimx, hy = 0.5f * b.dimy, hz = 0.5f * b.dimz;
+    const double dex = (double)hx * d20, dey = (double)hy * d21, dez = (double)hz * d22;
+    const double extent = fabs(dex) + fabs(dey) + fabs(dez);
+    const double zlo = (double)b.pz - extent;           // lowest keypoint  (z_min)
+    const double zhi = (double)b.pz + extent;           // highest keypoint (z_max)
+    const float r20 = (float)d20, r21 = (float)d21, r22 = (float)d22;
+    const float ex = (float)dex, ey = (float)dey, ez = (float)dez;
+    // The quaternion is used as given (N7).  With |q|^2 = 1 + e the matrix above is
+    // R = R^ + e (R^ - I) for the true rotation R^, hence exactly
+    //     R R^T = I + kappa (2I - R^ - R^T),   |R[:,2]|^2 = 1 + 2 kappa (1 - R^22),   kappa = e + e^2.
+    // e ~ 1e-7 for an fp32-rounded unit quaternion: invisible to fp32 arithmetic, but the fp64
+    // reference carries it into two terms that otherwise cancel exactly (below), so it is
+    // evaluated here in fp64 and applied analytically.
+    const double qerr = ((dqx * dqx + dqy * dqy) + (dqz * dqz + dqw * dqw)) - 1.0;
+    const float qe = (float)qerr;
+    const float kappa = (float)(qerr + qerr * qerr);
+
+    // ---- A3: submersion ratio (numba_hydrodynamics.py:86-96) ----
+    const bool dry_by_extent = zlo >= 0.0;
+    const bool fully_in = zhi <= 0.0;
+    const float height = (float)(extent + extent);
+    float ratio = fminf(1.0f, (float)(-zlo) * fast_rcp(height));
+    if (height < kHeightEps) ratio = 1.0f;              // z_lo < 0 is known here
+    if (fully_in) ratio = 1.0f;
+    if (dry_by_extent) ratio = 0.0f;
+    const bool wet = ratio > kDryEps;
+    o.wet = wet;
+
+    // ---- A3: centre of buoyancy from integer lattice sums (:69-84,99-103) ----
+    // z_ijk < 0 for lattice index (i,j,k); S_a = sum of index a over wet points.
+    float s_i = 0.0f, s_j = 0.0f, s_k = 0.0f, cnt = 0.0f;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            const float zij = b.pz + (float)i * ex + (float)j * ey;
+#pragma unroll
+            for (int k = -1; k <= 1; ++k) {
+                const float m = (zij + (float)k * ez < 0.0f) ? 1.0f : 0.0f;
+                cnt += m;
+                if (i != 0) s_i += (float)i * m;
+                if (j != 0) s_j += (float)j * m;
+                if (k != 0) s_k += (float)k * m;
+            }
+        }
+    }
+    const bool partial = !dry_by_extent && !fully_in && cnt > 0.0f;
+    const float inv_cnt = partial ? fast_rcp(cnt) : 0.0f;
+    const float lbx = hx * s_i * inv_cnt, lby = hy * s_j * inv_cnt, lbz = hz * s_k * inv_cnt;   // body frame
+    float armb_x = r00 * lbx + r01 * lby + r02 * lbz;
+    float armb_y = r10 * lbx + r11 * lby + r12 * lbz;
+    float armb_z = r20 * lbx + r21 * lby + r22 * lbz;
+
+    // ---- A5: buoyancy (:282) ----
+    const float volume = b.dimx * b.dimy * b.dimz;
+    const float buoy_z = rho * (ratio * volume) * g;
+
+    // ---- A6: speed and direction (:285-289) ----
+    const float speed = fast_sqrt(b.vx * b.vx + b.vy * b.vy + b.vz * b.vz);
+    const bool moving = speed > kSpeedEps;
+    const float inv_speed = moving ? fast_rcp(speed) : 0.0f;
+    const float dx = b.vx * inv_speed, dy = b.vy * inv_speed, dz = b.vz * inv_speed;   // v_hat (0 at rest)
+
+    // ---- A7: projected area + centre of pressure (:108-143) ----
+    // u = R^T v_hat; face (axis a, sign s) has alignment -s*u_a and centre height p_z + s*e_a.
+    const float ux = r00 * dx + r10 * dy + r20 * dz;
+    const float uy = r01 * dx + r11 * dy + r21 * dz;
+    const float uz = r02 * dx + r12 * dy + r22 * dz;
+    const float sx = (ux < 0.0f) ? 1.0f : -1.0f;        // sign of the face opposing the flow
+    const float sy = (uy < 0.0f) ? 1.0f : -1.0f;
+    const float sz = (uz < 0.0f) ? 1.0f : -1.0f;
+    const float fax = ((ux != 0.0f) && (b.pz + sx * ex < 0.0f)) ? fabsf(ux) * (b.dimy * b.dimz) : 0.0f;
+    const float fay = ((uy != 0.0f) && (b.pz + sy * ey < 0.0f)) ? fabsf(uy) * (b.dimx * b.dimz) : 0.0f;
+    const float faz = ((uz != 0.0f) && (b.pz + sz * ez < 0.0f)) ? fabsf(uz) * (b.dimx * b.dimy) : 0.0f;
+    const float area = fax + fay + faz;                 // 0 at rest (u = 0): N1 completion
+    const bool has_area = area > kAreaEps;
+    const float inv_area = has_area ? fast_rcp(area) : 0.0f;
+    const float lpx = sx * hx * fax * inv_area, lpy = sy * hy * fay * inv_area, lpz = sz * hz * faz * inv_area;
+    float armp_x = r00 * lpx + r01 * lpy + r02 * lpz;
+    float armp_y = r10 * lpx + r11 * lpy + r12 * lpz;
+    float armp_z = r20 * lpx + r21 * lpy + r22 * lpz;
+    if (!has_area) { armp_x = armb_x; armp_y = armb_y; armp_z = armb_z; }     // cop = cob (:115,140)
+    // arm_p x v_hat without cancellation.  h_a * area_a = V/2 on every axis, so
+    //     arm_p = -(V/2A) R W u,   u = R^T v_hat,   W = diag(face of axis a opposes the flow and is wet)
+    // which is parallel to v_hat (no torque from drag) when all three opposing faces are wet, up
+    // to the non-orthogonality of R.  With a = W u, c = (I - W) u (complementary supports, so
+    // X = a x c has ONE product per component) and Y = a x v_hat, to first order in e = |q|^2 - 1:
+    //     (R a) x v_hat = R X + e [ (X - R X) + (R Y - Y) ]
+    const bool cx = fax != 0.0f, cy = fay != 0.0f, cz = faz != 0.0f;
+    const float wux = cx ? ux : 0.0f, wuy = cy ? uy : 0.0f, wuz = cz ? uz : 0.0f;     // a = W u
+    const float gux = cx ? 0.0f : ux, guy = cy ? 0.0f : uy, guz = cz ? 0.0f : uz;     // c = (I-W) u
+    const float Xx = wuy * guz - wuz * guy, Xy = wuz * gux - wux * guz, Xz = wux * guy - wuy * gux;
+    const float Yx = wuy * dz - wuz * dy, Yy = wuz * dx - wux * dz, Yz = wux * dy - wuy * dx;
+    const float RXx = r00 * Xx + r01 * Xy + r02 * Xz, RXy = r10 * Xx + r11 * Xy + r12 * Xz, RXz = r20 * Xx + r21 * Xy + r22 * Xz;
+    const float RYx = r00 * Yx + r01 * Yy + r02 * Yz, RYy = r10 * Yx + r11 * Yy + r12 * Yz, RYz = r20 * Yx + r21 * Yy + r22 * Yz;
+    const float nhva = -0.5f * (b.dimx * b.dimy * b.dimz) * inv_area;              // -(V/2A)
+    float pxv_x = nhva * (RXx + qe * ((Xx - RXx) + (RYx - Yx)));                  // arm_p x v_hat
+    float pxv_y = nhva * (RXy + qe * ((Xy - RXy) + (RYy - Yy)));
+    float pxv_z = nhva * (RXz + qe * ((Xz - RXz) + (RYz - Yz)));
+    if (!has_area) {
+        pxv_x = armb_y * dz - armb_z * dy; pxv_y = armb_z * dx - armb_x * dz; pxv_z = armb_x * dy - armb_y * dx;
+    }
+
+    // ---- A8: hybrid drag (:146-182).  quad = -(1/2 rho s^2 Cd A) v_hat = -(1/2 rho s Cd A) v ----
+    const float half_rho = 0.5f * rho;
+    const float lin_quad = moving ? half_rho * speed * b.cd_lin * area : 0.0f;
+    const float lin_scale = (speed < kLowSpeed) ? speed * kInvLowSpeed : 1.0f;
+    const float lin_k = -(lin_quad + b.damp_lin * lin_scale) * ratio;
+    const float wspeed = fast_sqrt(b.wx * b.wx + b.wy * b.wy + b.wz * b.wz);
+    const float ang_quad = (wspeed > kSpeedEps) ? half_rho * wspeed * b.cd_ang * volume : 0.0f;
+    const float ang_scale = (wspeed < kLowSpeed) ? wspeed * kInvLowSpeed : 1.0f;
+    const float ang_k = -(ang_quad + b.damp_ang * ang_scale) * ratio;
+
+    // ---- A9: lift (:185-217) ----
+    // up = R[:,2]; d = clamp(-up.v_hat); C_L = sin(2 asin d) = 2 d sqrt((1-d)(1+d));
+    // dir = (v_hat x up) x v_hat / |v_hat x up| = (up |v_hat|^2 + d_raw v_hat) / |v_hat x up|
+    const float d_raw = -(r02 * dx + r12 * dy + r22 * dz);
+    // 1 - d^2 is taken from |v_hat x up|^2 = |up|^2 - d^2 (no cancellation as |d| -> 1):
+    //     sqrt(1 - d^2) / |axis| = sqrt(max(0, 1 - eta / |axis|^2)),  eta = |up|^2 - 1 = 2 kappa (1 - R22).
+    const float dcl = fminf(1.0f, fmaxf(-1.0f, d_raw));
+    const float axx = dy * r22 - dz * r12, axy = dz * r02 - dx * r22, axz = dx * r12 - dy * r02;
+    const float n_axis2 = axx * axx + axy * axy + axz * axz;
+    const float n_axis = fast_sqrt(n_axis2);
+    const bool lift_on = !(speed < kSpeedEps) && !(n_axis < kAxisEps);
+    const float eta = 2.0f * kappa * (1.0f - r22);
+    const float clamp_on = (fabsf(d_raw) < 1.0f) ? 1.0f : 0.0f;    // |d| >= 1 -> asin(+-1): C_L = sin(+-pi) = 0
+    const float c_l_over_n = 2.0f * dcl * clamp_on * fast_sqrt(fmaxf(0.0f, 1.0f - eta * fast_rcp(n_axis2)));
+    const float vhat2 = dx * dx + dy * dy + dz * dz;
+    const float lift_k = lift_on ? (half_rho * speed * speed * c_l_over_n * area * b.lift) * ratio : 0.0f;
+
+    // ---- A10: added mass (:220-253; diagonal of numba_hydrodynamics_wrapper.py:101-112) ----
+    const float rv = volume * rho;
+    const float m_lin = rv * b.am_lin;
+    const float m_ang = rv * b.am_ang;
+    const float d2x = b.dimx * b.dimx, d2y = b.dimy * b.dimy, d2z = b.dimz * b.dimz;
+    const float abx = r00 * b.ax + r10 * b.ay + r20 * b.az;         // R^T a
+    const float aby = r01 * b.ax + r11 * b.ay + r21 * b.az;
+    const float abz = r02 * b.ax + r12 * b.ay + r22 * b.az;
+    const float bbx = r00 * b.bx + r10 * b.by + r20 * b.bz;         // R^T alpha
+    const float bby = r01 * b.bx + r11 * b.by + r21 * b.bz;
+    const float bbz = r02 * b.bx + r12 * b.by + r22 * b.bz;
+    const float kf = -m_lin * ratio;
+    const float flx = kf * abx, fly = kf * aby, flz = kf * abz;
+    const float kt = -m_ang * ratio;
+    const float tlx = kt * (d2y + d2z) * bbx, tly = kt * (d2x + d2z) * bby, tlz = kt * (d2x + d2y) * bbz;
+
+    // ---- A4: dry bodies return zeros for every output (:277-279) ----
+    // (selects, not multiplies: a dry body must give exact zeros whatever the rest evaluated to)
+#define HYDRO_LIVE(x) (wet ? (x) : 0.0f)
+    o.ratio = HYDRO_LIVE(ratio);
+    o.buoy_z = HYDRO_LIVE(buoy_z);
+    o.drag_fx = HYDRO_LIVE(lin_k * b.vx); o.drag_fy = HYDRO_LIVE(lin_k * b.vy); o.drag_fz = HYDRO_LIVE(lin_k * b.vz);
+    o.drag_tx = HYDRO_LIVE(ang_k * b.wx); o.drag_ty = HYDRO_LIVE(ang_k * b.wy); o.drag_tz = HYDRO_LIVE(ang_k * b.wz);
+    o.lift_fx = HYDRO_LIVE(lift_k * (r02 * vhat2 + d_raw * dx));
+    o.lift_fy = HYDRO_LIVE(lift_k * (r12 * vhat2 + d_raw * dy));
+    o.lift_fz = HYDRO_LIVE(lift_k * (r22 * vhat2 + d_raw * dz));
+    o.am_fx = HYDRO_LIVE(r00 * flx + r01 * fly + r02 * flz);
+    o.am_fy = HYDRO_LIVE(r10 * flx + r11 * fly + r12 * flz);
+    o.am_fz = HYDRO_LIVE(r20 * flx + r21 * fly + r22 * flz);
+    o.am_tx = HYDRO_LIVE(r00 * tlx + r01 * tly + r02 * tlz);
+    o.am_ty = HYDRO_LIVE(r10 * tlx + r11 * tly + r12 * tlz);
+    o.am_tz = HYDRO_LIVE(r20 * tlx + r21 * tly + r22 * tlz);
+    o.armb_x = HYDRO_LIVE(armb_x); o.armb_y = HYDRO_LIVE(armb_y); o.armb_z = HYDRO_LIVE(armb_z);
+    o.armp_x = HYDRO_LIVE(armp_x); o.armp_y = HYDRO_LIVE(armp_y); o.armp_z = HYDRO_LIVE(armp_z);
+    const float ks = lin_k * speed;                                 // drag_force = ks * v_hat
+    o.dragarm_tx = HYDRO_LIVE(ks * pxv_x); o.dragarm_ty = HYDRO_LIVE(ks * pxv_y); o.dragarm_tz = HYDRO_LIVE(ks * pxv_z);
+#undef HYDRO_LIVE
+    return o;
+}
+
+struct Wrench { float fx, fy, fz, tx, ty, tz; };
+
+// A14-A15: lever-arm torques, sum, safety clamp (hydrodynamics_behavior.py:212-226).
+HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass)
+{
+    const float fx = (o.drag_fx + o.lift_fx) + o.am_fx;
+    const float fy = (o.drag_fy + o.lift_fy) + o.am_fy;
+    const float fz = (o.buoy_z + (o.drag_fz + o.lift_fz)) + o.am_fz;
+    // tau = arm_b x (0,0,Fb) + arm_p x F_drag + arm_p x F_lift + tau_drag + tau_am
+    const float tx = o.armb_y * o.buoy_z + o.dragarm_tx + (o.armp_y * o.lift_fz - o.armp_z * o.lift_fy) + o.drag_tx + o.am_tx;
+    const float ty = -o.armb_x * o.buoy_z + o.dragarm_ty + (o.armp_z * o.lift_fx - o.armp_x * o.lift_fz) + o.drag_ty + o.am_ty;
+    const float tz = o.dragarm_tz + (o.armp_x * o.lift_fy - o.armp_y * o.lift_fx) + o.drag_tz + o.am_tz;
+    const float f_mag = fast_sqrt(fx * fx + fy * fy + fz * fz);
+    const float scale = fminf(1.0f, mass * kMaxAccel * fast_rcp(f_mag + kClampEps));
+    Wrench w;
+    w.fx = fx * scale; w.fy = fy * scale; w.fz = fz * scale;
+    w.tx = tx * scale; w.ty = ty * scale; w.tz = tz * scale;
+    return w;
+}
+
+}  // namespace hydro

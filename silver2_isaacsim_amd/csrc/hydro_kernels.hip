@@ -1,0 +1,871 @@
+// gfx950 (MI355X / CDNA4) kernels and C ABI of libhydro.so - see include/hydro.h.
+//
+// Every kernel is elementwise per rigid body and HBM-bound (about 400 VALU
+// instructions against 144 B per body-step): no MFMA anywhere.  What matters is
+//   * struct-of-arrays state so that each wave-instruction reads a contiguous run
+//     of one field (4/8/16 B per lane = 256 B / 512 B / 1 KiB per wave64 request);
+//   * all of a body's ~30 loads issued before the first use, so a wave has its
+//     whole working set in flight at once (the kernels are single-pass, latency is
+//     hidden by occupancy: 4-8 waves per SIMD);
+//   * nothing re-read and nothing written but the wrench (24 B per body).
+// The array-of-structs entry point (the simulator's tensor layout) stages the
+// transposition through LDS; the kinetic-energy reduction uses wave64 shuffles,
+// LDS across the block's four waves and a fixed-order second stage.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/hydro.h"
+#include "hydro_body.h"
+
+namespace {
+
+constexpr int kBlock = 256;                // 4 waves of 64 lanes
+constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
+
+// --------------------------------------------------------------------------
+// vector load / store helpers: VEC consecutive bodies of one SoA field per lane
+// --------------------------------------------------------------------------
+template <int VEC> struct FVec;
+template <> struct FVec<1> { using type = float; };
+template <> struct FVec<2> { using type = float2; };
+template <> struct FVec<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i, float (&out)[VEC])
+{
+    using V = typename FVec<VEC>::type;
+    const V v = *reinterpret_cast<const V*>(p + i);
+    const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = f[j];
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* __restrict__ p, int64_t i, const float (&in)[VEC])
+{
+    using V = typename FVec<VEC>::type;
+    V v;
+    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = in[j];
+    *reinterpret_cast<V*>(p + i) = v;
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_f16(const __half* __restrict__ p, int64_t i, float (&out)[VEC])
+{
+    if constexpr (VEC == 1) {
+        out[0] = __half2float(p[i]);
+    } else if constexpr (VEC == 2) {
+        const __half2 h = *reinterpret_cast<const __half2*>(p + i);
+        out[0] = __low2float(h); out[1] = __high2float(h);
+    } else {
+        const uint2 raw = *reinterpret_cast<const uint2*>(p + i);
+        const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
+        const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
+        out[0] = __low2float(a); out[1] = __high2float(a); out[2] = __low2float(b); out[3] = __high2float(b);
+    }
+}
+
+template <int VEC, bool HALF>
+__device__ __forceinline__ void load_coef(const void* __restrict__ p, int64_t i, float (&out)[VEC])
+{
+    if constexpr (HALF) load_f16<VEC>(static_cast<const __half*>(p), i, out);
+    else load_f32<VEC>(static_cast<const float*>(p), i, out);
+}
+
+template <bool HALF>
+__device__ __forceinline__ float load_coef1(const void* __restrict__ p, int64_t i)
+{
+    if constexpr (HALF) return __half2float(static_cast<const __half*>(p)[i]);
+    else return static_cast<const float*>(p)[i];
+}
+
+// --------------------------------------------------------------------------
+// kernel arguments (passed by value in the kernarg segment: pointers land in SGPRs)
+// --------------------------------------------------------------------------
+struct SoaArgs {
+    const float* st[HYDRO_STATE_FIELDS];
+    const float* pv[HYDRO_PREV_FIELDS];      // previous velocity (read)
+    float* pv_out[HYDRO_PREV_FIELDS];        // where to store this step's velocity (WRITE_PREV)
+    const float* dims[3];
+    const void* coef[7];                     // float or __half
+    const float* mass;
+    float* out[HYDRO_WRENCH_FIELDS];
+    float rho, g, inv_dt;
+    int64_t n;
+};
+
+// One body from already-loaded scalars.
+__device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
+                                                     const float (&d)[3], const float (&c)[7], float mass,
+                                                     float rho, float g, float inv_dt)
+{
+    hydro::BodyIn b;
+    b.px = s[0]; b.py = s[1]; b.pz = s[2];
+    b.qx = s[3]; b.qy = s[4]; b.qz = s[5]; b.qw = s[6];
+    b.vx = s[7]; b.vy = s[8]; b.vz = s[9];
+    b.wx = s[10]; b.wy = s[11]; b.wz = s[12];
+    // A13: finite-difference acceleration (hydrodynamics_behavior.py:200-202)
+    b.ax = (s[7] - pv[0]) * inv_dt; b.ay = (s[8] - pv[1]) * inv_dt; b.az = (s[9] - pv[2]) * inv_dt;
+    b.bx = (s[10] - pv[3]) * inv_dt; b.by = (s[11] - pv[4]) * inv_dt; b.bz = (s[12] - pv[5]) * inv_dt;
+    b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
+    b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
+    b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
+    const hydro::BodyOut o = hydro::solve_body(b, rho, g);
+    return hydro::assemble_wrench(o, mass);
+}
+
+// --------------------------------------------------------------------------
+// fused wrench, struct-of-arrays.  Each lane owns VEC consecutive bodies.
+// Algorithmic traffic per body: 52 B state + 24 B previous velocity + 44 B (30 B
+// with fp16 coefficients) parameters in, 24 B wrench out (+24 B if WRITE_PREV).
+// --------------------------------------------------------------------------
+template <int VEC, bool HALF, bool WRITE_PREV>
+__global__ void __launch_bounds__(kBlock) wrench_soa_kernel(const SoaArgs a)
+{
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+    if (base >= a.n) return;
+
+    float st[HYDRO_STATE_FIELDS][VEC], pv[HYDRO_PREV_FIELDS][VEC], dm[3][VEC], cf[7][VEC], ms[VEC];
+    const bool full = (base + VEC <= a.n);
+    if (full) {
+#pragma unroll
+        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) load_f32<VEC>(a.st[f], base, st[f]);
+#pragma unroll
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) load_f32<VEC>(a.pv[f], base, pv[f]);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) load_f32<VEC>(a.dims[f], base, dm[f]);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) load_coef<VEC, HALF>(a.coef[f], base, cf[f]);
+        load_f32<VEC>(a.mass, base, ms);
+    } else {
+        // ragged tail (only the last lane with work): element-wise, padded with a benign body
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool ok = base + j < a.n;
+            const int64_t i = ok ? base + j : base;
+#pragma unroll
+            for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) st[f][j] = a.st[f][i];
+#pragma unroll
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f][j] = a.pv[f][i];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) dm[f][j] = a.dims[f][i];
+#pragma unroll
+            for (int f = 0; f < 7; ++f) cf[f][j] = load_coef1<HALF>(a.coef[f], i);
+            ms[j] = a.mass[i];
+        }
+    }
+
+    float out[HYDRO_WRENCH_FIELDS][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        float s[HYDRO_STATE_FIELDS], p[HYDRO_PREV_FIELDS], d[3], c[7];
+#pragma unroll
+        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = st[f][j];
+#pragma unroll
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) p[f] = pv[f][j];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) d[f] = dm[f][j];
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = cf[f][j];
+        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt);
+        out[0][j] = w.fx; out[1][j] = w.fy; out[2][j] = w.fz;
+        out[3][j] = w.tx; out[4][j] = w.ty; out[5][j] = w.tz;
+    }
+
+    if (full) {
+#pragma unroll
+        for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) store_f32<VEC>(a.out[f], base, out[f]);
+        if constexpr (WRITE_PREV) {
+#pragma unroll
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) store_f32<VEC>(a.pv_out[f], base, st[7 + f]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (base + j < a.n) {
+#pragma unroll
+                for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) a.out[f][base + j] = out[f][j];
+                if constexpr (WRITE_PREV) {
+#pragma unroll
+                    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv_out[f][base + j] = st[7 + f][j];
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// fused wrench on the simulator's array-of-structs tensors.
+// One block = 256 consecutive bodies.  positions (256x3) and velocities (256x6) are read
+// as whole 16-B chunks (fully coalesced), parked in LDS and picked up per body with
+// conflict-free strides (3 and 6 dwords: odd / 2*odd); orientations are one float4 per
+// lane already.  Forces and torques take the same road back.  Previous velocity is the
+// engine's SoA (read, then overwritten with this step's velocity).
+// --------------------------------------------------------------------------
+struct AosArgs {
+    const float* pos;       // (n,3)
+    const float* quat_wxyz; // (n,4)
+    const float* vel;       // (n,6)
+    float* force;           // (n,3)
+    float* torque;          // (n,3)
+    float* pv[HYDRO_PREV_FIELDS];
+    const float* dims[3];
+    const void* coef[7];
+    const float* mass;
+    float rho, g, inv_dt;
+    int64_t n;
+};
+
+template <bool HALF>
+__global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kBlock * 6];     // 6 KiB: velocities, then F|T
+    __shared__ __attribute__((aligned(16))) float lds_pos[kBlock * 3]; // 3 KiB
+
+    const int t = threadIdx.x;
+    const int64_t block0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t i = block0 + t;
+    const int64_t left = a.n - block0;                      // bodies in this block (>=1)
+    const bool whole = left >= kBlock;
+
+    if (whole) {
+        const float4* p4 = reinterpret_cast<const float4*>(a.pos + block0 * 3);
+        const float4* v4 = reinterpret_cast<const float4*>(a.vel + block0 * 6);
+        if (t < kBlock * 3 / 4) reinterpret_cast<float4*>(lds_pos)[t] = p4[t];
+        reinterpret_cast<float4*>(lds)[t] = v4[t];
+        if (t < kBlock * 6 / 4 - kBlock) reinterpret_cast<float4*>(lds)[t + kBlock] = v4[t + kBlock];
+    } else {
+        for (int64_t k = t; k < left * 3; k += kBlock) lds_pos[k] = a.pos[block0 * 3 + k];
+        for (int64_t k = t; k < left * 6; k += kBlock) lds[k] = a.vel[block0 * 6 + k];
+    }
+    __syncthreads();
+
+    const bool live = i < a.n;
+    const int64_t ic = live ? i : a.n - 1;                  // clamp: idle lanes redo the last body
+    const int tc = (int)(ic - block0);
+    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7];
+    s[0] = lds_pos[3 * tc]; s[1] = lds_pos[3 * tc + 1]; s[2] = lds_pos[3 * tc + 2];
+    const float4 q = reinterpret_cast<const float4*>(a.quat_wxyz)[ic];   // w x y z
+    s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x;                      // -> x y z w  (hydrodynamics_behavior.py:194)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * tc + f];
+#pragma unroll
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = a.pv[f][ic];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) d[f] = a.dims[f][ic];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) c[f] = load_coef1<HALF>(a.coef[f], ic);
+    const float mass = a.mass[ic];
+
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
+
+    if (live) {
+#pragma unroll
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv[f][i] = s[7 + f];
+    }
+    __syncthreads();                                        // everyone has read its velocity
+    lds[3 * t] = w.fx; lds[3 * t + 1] = w.fy; lds[3 * t + 2] = w.fz;
+    lds[kBlock * 3 + 3 * t] = w.tx; lds[kBlock * 3 + 3 * t + 1] = w.ty; lds[kBlock * 3 + 3 * t + 2] = w.tz;
+    __syncthreads();
+    if (whole) {
+        if (t < kBlock * 3 / 4) {
+            reinterpret_cast<float4*>(a.force + block0 * 3)[t] = reinterpret_cast<const float4*>(lds)[t];
+            reinterpret_cast<float4*>(a.torque + block0 * 3)[t] = reinterpret_cast<const float4*>(lds + kBlock * 3)[t];
+        }
+    } else {
+        for (int64_t k = t; k < left * 3; k += kBlock) {
+            a.force[block0 * 3 + k] = lds[k];
+            a.torque[block0 * 3 + k] = lds[kBlock * 3 + k];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// component mode (compatibility / debug surface, not a benchmark mode)
+// --------------------------------------------------------------------------
+struct CompArgs {
+    const float* st[HYDRO_STATE_FIELDS];
+    const float* acc[HYDRO_PREV_FIELDS];
+    const float* dims[3];
+    const void* coef[7];
+    float* out[HYDRO_COMP_FIELDS];
+    float* ratio;
+    float rho, g;
+    int64_t n;
+};
+
+template <bool HALF>
+__global__ void __launch_bounds__(kBlock) components_kernel(const CompArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    hydro::BodyIn b;
+    b.px = a.st[0][i]; b.py = a.st[1][i]; b.pz = a.st[2][i];
+    b.qx = a.st[3][i]; b.qy = a.st[4][i]; b.qz = a.st[5][i]; b.qw = a.st[6][i];
+    b.vx = a.st[7][i]; b.vy = a.st[8][i]; b.vz = a.st[9][i];
+    b.wx = a.st[10][i]; b.wy = a.st[11][i]; b.wz = a.st[12][i];
+    b.ax = a.acc[0][i]; b.ay = a.acc[1][i]; b.az = a.acc[2][i];
+    b.bx = a.acc[3][i]; b.by = a.acc[4][i]; b.bz = a.acc[5][i];
+    b.dimx = a.dims[0][i]; b.dimy = a.dims[1][i]; b.dimz = a.dims[2][i];
+    b.cd_lin = load_coef1<HALF>(a.coef[0], i); b.cd_ang = load_coef1<HALF>(a.coef[1], i);
+    b.damp_lin = load_coef1<HALF>(a.coef[2], i); b.damp_ang = load_coef1<HALF>(a.coef[3], i);
+    b.lift = load_coef1<HALF>(a.coef[4], i); b.am_lin = load_coef1<HALF>(a.coef[5], i);
+    b.am_ang = load_coef1<HALF>(a.coef[6], i);
+    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g);
+    const float live = o.wet ? 1.0f : 0.0f;
+    a.out[0][i] = 0.0f; a.out[1][i] = 0.0f; a.out[2][i] = o.buoy_z;
+    a.out[3][i] = o.drag_fx; a.out[4][i] = o.drag_fy; a.out[5][i] = o.drag_fz;
+    a.out[6][i] = o.lift_fx; a.out[7][i] = o.lift_fy; a.out[8][i] = o.lift_fz;
+    a.out[9][i] = o.drag_tx; a.out[10][i] = o.drag_ty; a.out[11][i] = o.drag_tz;
+    a.out[12][i] = o.am_fx; a.out[13][i] = o.am_fy; a.out[14][i] = o.am_fz;
+    a.out[15][i] = o.am_tx; a.out[16][i] = o.am_ty; a.out[17][i] = o.am_tz;
+    // world-space centres; zeros when dry (Numba semantics, numba_hydrodynamics.py:277-279)
+    a.out[18][i] = live * (b.px + o.armb_x); a.out[19][i] = live * (b.py + o.armb_y); a.out[20][i] = live * (b.pz + o.armb_z);
+    a.out[21][i] = live * (b.px + o.armp_x); a.out[22][i] = live * (b.py + o.armp_y); a.out[23][i] = live * (b.pz + o.armp_z);
+    if (a.ratio) a.ratio[i] = o.ratio;
+}
+
+// --------------------------------------------------------------------------
+// kinetic energy: wave64 shuffle -> LDS across the 4 waves -> one fp64 partial pair per
+// block -> fixed-order second stage (deterministic, no atomics).
+// --------------------------------------------------------------------------
+struct KeArgs {
+    const float* st[HYDRO_STATE_FIELDS];
+    const float* dims[3];
+    const float* mass;
+    double* partials;      // [2 * kKeBlocks]
+    double* out;           // [2]
+    int rotational;
+    int64_t n;
+};
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+__global__ void __launch_bounds__(kBlock) ke_partial_kernel(const KeArgs a)
+{
+    __shared__ double red[2][kBlock / 64];
+    double lin = 0.0, rot = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const float m = a.mass[i];
+        const float vx = a.st[7][i], vy = a.st[8][i], vz = a.st[9][i];
+        lin += 0.5 * (double)m * ((double)vx * vx + (double)vy * vy + (double)vz * vz);
+        if (a.rotational) {
+            const float qx = a.st[3][i], qy = a.st[4][i], qz = a.st[5][i], qw = a.st[6][i];
+            const float wx = a.st[10][i], wy = a.st[11][i], wz = a.st[12][i];
+            const float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+            const float xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
+            const float sx = qw * x2, sy = qw * y2, sz = qw * z2;
+            // w_b = R^T w
+            const float bx = (1.0f - (yy + zz)) * wx + (xy + sz) * wy + (xz - sy) * wz;
+            const float by = (xy - sz) * wx + (1.0f - (xx + zz)) * wy + (yz + sx) * wz;
+            const float bz = (xz + sy) * wx + (yz - sx) * wy + (1.0f - (xx + yy)) * wz;
+            const float dx = a.dims[0][i], dy = a.dims[1][i], dz = a.dims[2][i];
+            const double k = (double)m / 12.0;
+            rot += 0.5 * k * ((double)(dy * dy + dz * dz) * bx * bx + (double)(dx * dx + dz * dz) * by * by
+                              + (double)(dx * dx + dy * dy) * bz * bz);
+        }
+    }
+    lin = wave_sum(lin);
+    rot = wave_sum(rot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = lin; red[1][wave] = rot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double l = 0.0, r = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { l += red[0][w]; r += red[1][w]; }
+        a.partials[blockIdx.x] = l;
+        a.partials[kKeBlocks + blockIdx.x] = r;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) ke_final_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+{
+    __shared__ double red[2][kBlock];
+    double l = 0.0, r = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += kBlock) { l += partials[k]; r += partials[kKeBlocks + k]; }
+    red[0][threadIdx.x] = l; red[1][threadIdx.x] = r;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+}
+
+// --------------------------------------------------------------------------
+// explicit rigid-body step (stands in for PhysX in closed-loop runs)
+// --------------------------------------------------------------------------
+struct IntArgs {
+    const float* si[HYDRO_STATE_FIELDS];
+    const float* w[HYDRO_WRENCH_FIELDS];
+    float* so[HYDRO_STATE_FIELDS];
+    const float* dims[3];
+    const float* mass;
+    float g, dt;
+    int64_t n;
+};
+
+__global__ void __launch_bounds__(kBlock) integrate_kernel(const IntArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    float s[HYDRO_STATE_FIELDS], f[HYDRO_WRENCH_FIELDS];
+#pragma unroll
+    for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) s[k] = a.si[k][i];
+#pragma unroll
+    for (int k = 0; k < HYDRO_WRENCH_FIELDS; ++k) f[k] = a.w[k][i];
+    const float m = a.mass[i], inv_m = 1.0f / m, dt = a.dt;
+    const float dx = a.dims[0][i], dy = a.dims[1][i], dz = a.dims[2][i];
+    // linear: semi-implicit Euler, gravity along -z
+    const float vx = s[7] + dt * (f[0] * inv_m), vy = s[8] + dt * (f[1] * inv_m), vz = s[9] + dt * (f[2] * inv_m - a.g);
+    const float px = s[0] + dt * vx, py = s[1] + dt * vy, pz = s[2] + dt * vz;
+    // angular, body frame: I w' = tau_b - w_b x (I w_b), box inertia
+    const float qx = s[3], qy = s[4], qz = s[5], qw = s[6];
+    const float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    const float xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
+    const float sx = qw * x2, sy = qw * y2, sz = qw * z2;
+    const float r00 = 1.0f - (yy + zz), r01 = xy - sz, r02 = xz + sy;
+    const float r10 = xy + sz, r11 = 1.0f - (xx + zz), r12 = yz - sx;
+    const float r20 = xz - sy, r21 = yz + sx, r22 = 1.0f - (xx + yy);
+    const float k = m * (1.0f / 12.0f);
+    const float ix = k * (dy * dy + dz * dz), iy = k * (dx * dx + dz * dz), iz = k * (dx * dx + dy * dy);
+    const float wbx = r00 * s[10] + r10 * s[11] + r20 * s[12];
+    const float wby = r01 * s[10] + r11 * s[11] + r21 * s[12];
+    const float wbz = r02 * s[10] + r12 * s[11] + r22 * s[12];
+    const float tbx = r00 * f[3] + r10 * f[4] + r20 * f[5];
+    const float tby = r01 * f[3] + r11 * f[4] + r21 * f[5];
+    const float tbz = r02 * f[3] + r12 * f[4] + r22 * f[5];
+    const float nbx = wbx + dt * (tbx - (wby * (iz * wbz) - wbz * (iy * wby))) / ix;
+    const float nby = wby + dt * (tby - (wbz * (ix * wbx) - wbx * (iz * wbz))) / iy;
+    const float nbz = wbz + dt * (tbz - (wbx * (iy * wby) - wby * (ix * wbx))) / iz;
+    const float wx = r00 * nbx + r01 * nby + r02 * nbz;
+    const float wy = r10 * nbx + r11 * nby + r12 * nbz;
+    const float wz = r20 * nbx + r21 * nby + r22 * nbz;
+    // q' = normalise(q + dt/2 * (w,0) (x) q)
+    const float h = 0.5f * dt;
+    float nqx = qx + h * (wx * qw + wy * qz - wz * qy);
+    float nqy = qy + h * (wy * qw + wz * qx - wx * qz);
+    float nqz = qz + h * (wz * qw + wx * qy - wy * qx);
+    float nqw = qw - h * (wx * qx + wy * qy + wz * qz);
+    const float inv_n = 1.0f / sqrtf(nqx * nqx + nqy * nqy + nqz * nqz + nqw * nqw);
+    nqx *= inv_n; nqy *= inv_n; nqz *= inv_n; nqw *= inv_n;
+    a.so[0][i] = px; a.so[1][i] = py; a.so[2][i] = pz;
+    a.so[3][i] = nqx; a.so[4][i] = nqy; a.so[5][i] = nqz; a.so[6][i] = nqw;
+    a.so[7][i] = vx; a.so[8][i] = vy; a.so[9][i] = vz;
+    a.so[10][i] = wx; a.so[11][i] = wy; a.so[12][i] = wz;
+}
+
+__global__ void __launch_bounds__(kBlock) to_half_kernel(const float* __restrict__ src, __half* __restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = __float2half_rn(src[i]);
+}
+
+}  // namespace
+
+// ==========================================================================
+// engine object + C ABI
+// ==========================================================================
+struct hydro_engine {
+    int device = 0;
+    int64_t capacity = 0;
+    int64_t stride = 0;            // padded field stride of the engine-owned SoA buffers (floats)
+    int64_t n_params = 0;          // bodies for which parameters have been set
+    float rho = 1025.0f, g = 9.81f;
+    bool half_coeffs = false;
+    float* params = nullptr;       // [11][stride] fp32
+    __half* coeffs16 = nullptr;    // [7][stride]
+    float* prev = nullptr;         // [6][stride]
+    double* ke_partials = nullptr; // [2 * kKeBlocks]
+    hipStream_t stream = nullptr;
+    int vec = 0;                   // 0 = default
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(hydro_engine* h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        if (e != hipSuccess) snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(h->err, sizeof h->err, "%s", what);
+    }
+    return code;
+}
+
+#define HYDRO_HIP(h, call, code)                                   \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return fail((h), (code), #call, e_); \
+    } while (0)
+
+inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int check_common(hydro_engine* h, int64_t n)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "n out of range (0 <= n <= capacity)");
+    if (n > h->n_params) return fail(h, HYDRO_E_STATE, "parameters not set for n bodies (call hydro_set_params_* first)");
+    return HYDRO_OK;
+}
+
+template <typename Args>
+void fill_params(hydro_engine* h, Args& a)
+{
+    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
+    for (int f = 0; f < 7; ++f)
+        a.coef[f] = h->half_coeffs ? static_cast<const void*>(h->coeffs16 + f * h->stride)
+                                   : static_cast<const void*>(h->params + (3 + f) * h->stride);
+}
+
+template <int VEC, bool WRITE_PREV>
+void launch_soa(hydro_engine* h, const SoaArgs& a, hipStream_t s)
+{
+    const int grid = grid_for(a.n, kBlock * VEC);
+    if (h->half_coeffs) hipLaunchKernelGGL((wrench_soa_kernel<VEC, true, WRITE_PREV>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((wrench_soa_kernel<VEC, false, WRITE_PREV>), dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+template <bool WRITE_PREV>
+int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float* const prev[], float* const prev_out[],
+             float dt, float* const wrench[], void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!state || !wrench || !prev) return fail(h, HYDRO_E_ARG, "null pointer table");
+    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (n == 0) return HYDRO_OK;
+    SoaArgs a;
+    int vec = h->vec ? h->vec : 2;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) {
+        if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field");
+        a.st[f] = state[f];
+        while (vec > 1 && !aligned_to(state[f], sizeof(float) * vec)) vec >>= 1;
+    }
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) {
+        if (!prev[f]) return fail(h, HYDRO_E_ARG, "null previous-velocity field");
+        a.pv[f] = prev[f];
+        a.pv_out[f] = prev_out ? prev_out[f] : nullptr;
+        while (vec > 1 && !aligned_to(prev[f], sizeof(float) * vec)) vec >>= 1;
+    }
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) {
+        if (!wrench[f]) return fail(h, HYDRO_E_ARG, "null wrench field");
+        a.out[f] = wrench[f];
+        while (vec > 1 && !aligned_to(wrench[f], sizeof(float) * vec)) vec >>= 1;
+    }
+    fill_params(h, a);
+    a.mass = h->params + 10 * h->stride;
+    a.rho = h->rho; a.g = h->g;
+    a.inv_dt = (float)(1.0 / (double)dt);
+    a.n = n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vec >= 4) launch_soa<4, WRITE_PREV>(h, a, s);
+    else if (vec == 2) launch_soa<2, WRITE_PREV>(h, a, s);
+    else launch_soa<1, WRITE_PREV>(h, a, s);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int copy_fields(hydro_engine* h, float* dst, int64_t dst_stride, const float* const src[], int nfields, int64_t n, int on_device)
+{
+    for (int f = 0; f < nfields; ++f) {
+        if (!src[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
+        HYDRO_HIP(h, hipMemcpyAsync(dst + f * dst_stride, src[f], sizeof(float) * n,
+                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream),
+                  HYDRO_E_LAUNCH);
+    }
+    return HYDRO_OK;
+}
+
+int set_params(hydro_engine* h, int64_t n, const float* const params[], int on_device, bool half)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (!params) return fail(h, HYDRO_E_ARG, "null pointer table");
+    if (n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "n out of range (0 <= n <= capacity)");
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    int rc = copy_fields(h, h->params, h->stride, params, HYDRO_PARAM_FIELDS, n, on_device);
+    if (rc) return rc;
+    if (half && n > 0) {
+        for (int f = 0; f < 7; ++f)
+            hipLaunchKernelGGL(to_half_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, h->stream,
+                               h->params + (3 + f) * h->stride, h->coeffs16 + f * h->stride, n);
+        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    }
+    // the source arrays may be pageable host memory that the caller frees right away
+    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    h->half_coeffs = half;
+    h->n_params = n;
+    return HYDRO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hydro_version(void) { return HYDRO_VERSION; }
+
+const char* hydro_status_string(int status)
+{
+    switch (status) {
+        case HYDRO_OK: return "HYDRO_OK";
+        case HYDRO_E_ARG: return "HYDRO_E_ARG";
+        case HYDRO_E_ALLOC: return "HYDRO_E_ALLOC";
+        case HYDRO_E_LAUNCH: return "HYDRO_E_LAUNCH";
+        case HYDRO_E_DEVICE: return "HYDRO_E_DEVICE";
+        case HYDRO_E_STATE: return "HYDRO_E_STATE";
+        default: return "HYDRO_E_UNKNOWN";
+    }
+}
+
+int hydro_device_count(int* count)
+{
+    if (!count) return HYDRO_E_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { *count = 0; return HYDRO_E_DEVICE; }
+    *count = c;
+    return HYDRO_OK;
+}
+
+int hydro_create(int device, int64_t capacity, hydro_t** out)
+{
+    if (!out || capacity <= 0) return HYDRO_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HYDRO_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return HYDRO_E_DEVICE;
+    hydro_engine* h = new (std::nothrow) hydro_engine();
+    if (!h) return HYDRO_E_ALLOC;
+    h->device = device;
+    h->capacity = capacity;
+    h->stride = (capacity + 1023) / 1024 * 1024;          // 4 KiB-aligned fields
+    const size_t fbytes = sizeof(float) * (size_t)h->stride;
+    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc(&h->params, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
+    ok = ok && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) == hipSuccess;
+    ok = ok && hipMalloc(&h->prev, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
+    ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * 2 * kKeBlocks) == hipSuccess;
+    ok = ok && hipMemsetAsync(h->prev, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+    if (!ok) { hydro_destroy(h); return HYDRO_E_ALLOC; }
+    *out = h;
+    return HYDRO_OK;
+}
+
+int hydro_destroy(hydro_t* h)
+{
+    if (!h) return HYDRO_E_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->params) (void)hipFree(h->params);
+    if (h->coeffs16) (void)hipFree(h->coeffs16);
+    if (h->prev) (void)hipFree(h->prev);
+    if (h->ke_partials) (void)hipFree(h->ke_partials);
+    delete h;
+    return HYDRO_OK;
+}
+
+const char* hydro_last_error(const hydro_t* h) { return h ? h->err : "null handle"; }
+
+int64_t hydro_capacity(const hydro_t* h) { return h ? h->capacity : 0; }
+
+int hydro_set_scene(hydro_t* h, float water_density, float gravity)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (!(water_density >= 0.0f) || !(gravity == gravity)) return fail(h, HYDRO_E_ARG, "bad scene scalars");
+    h->rho = water_density;
+    h->g = gravity;
+    return HYDRO_OK;
+}
+
+int hydro_set_params_f32(hydro_t* h, int64_t n, const float* const params[HYDRO_PARAM_FIELDS], int on_device)
+{
+    return set_params(h, n, params, on_device, false);
+}
+
+int hydro_set_params_f16(hydro_t* h, int64_t n, const float* const params[HYDRO_PARAM_FIELDS], int on_device)
+{
+    return set_params(h, n, params, on_device, true);
+}
+
+int hydro_reset_prev_velocity(hydro_t* h)
+{
+    if (!h) return HYDRO_E_ARG;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
+    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_get_prev_velocity(hydro_t* h, int64_t n, float* const prev[HYDRO_PREV_FIELDS], int on_device)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) {
+        if (!prev[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
+        HYDRO_HIP(h, hipMemcpyAsync(prev[f], h->prev + f * h->stride, sizeof(float) * n,
+                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream), HYDRO_E_LAUNCH);
+    }
+    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO_PREV_FIELDS], int on_device)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    int rc = copy_fields(h, h->prev, h->stride, prev, HYDRO_PREV_FIELDS, n, on_device);
+    if (rc) return rc;
+    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], float dt,
+                      float* const wrench[HYDRO_WRENCH_FIELDS], void* stream)
+{
+    if (!h) return HYDRO_E_ARG;
+    float* pv[HYDRO_PREV_FIELDS];
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = h->prev + f * h->stride;
+    return step_soa<true>(h, n, state, pv, pv, dt, wrench, stream);
+}
+
+int hydro_step_wrench_ext(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS],
+                          const float* const prev[HYDRO_PREV_FIELDS], float dt,
+                          float* const wrench[HYDRO_WRENCH_FIELDS], void* stream)
+{
+    if (!h) return HYDRO_E_ARG;
+    return step_soa<false>(h, n, state, prev, nullptr, dt, wrench, stream);
+}
+
+int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations_wxyz,
+                          const float* velocities, float dt, float* forces, float* torques, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!positions || !orientations_wxyz || !velocities || !forces || !torques) return fail(h, HYDRO_E_ARG, "null tensor pointer");
+    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!aligned_to(positions, 16) || !aligned_to(orientations_wxyz, 16) || !aligned_to(velocities, 16) ||
+        !aligned_to(forces, 16) || !aligned_to(torques, 16))
+        return fail(h, HYDRO_E_ARG, "array-of-structs tensors must be 16-byte aligned");
+    if (n == 0) return HYDRO_OK;
+    AosArgs a;
+    a.pos = positions; a.quat_wxyz = orientations_wxyz; a.vel = velocities; a.force = forces; a.torque = torques;
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv[f] = h->prev + f * h->stride;
+    fill_params(h, a);
+    a.mass = h->params + 10 * h->stride;
+    a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n, kBlock);
+    if (h->half_coeffs) hipLaunchKernelGGL(wrench_aos_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(wrench_aos_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS],
+                          const float* const accel[HYDRO_PREV_FIELDS], float* const comps[HYDRO_COMP_FIELDS],
+                          float* ratio, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!state || !accel || !comps) return fail(h, HYDRO_E_ARG, "null pointer table");
+    if (n == 0) return HYDRO_OK;
+    CompArgs a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field"); a.st[f] = state[f]; }
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) { if (!accel[f]) return fail(h, HYDRO_E_ARG, "null acceleration field"); a.acc[f] = accel[f]; }
+    for (int f = 0; f < HYDRO_COMP_FIELDS; ++f) { if (!comps[f]) return fail(h, HYDRO_E_ARG, "null component field"); a.out[f] = comps[f]; }
+    fill_params(h, a);
+    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.n = n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n, kBlock);
+    if (h->half_coeffs) hipLaunchKernelGGL(components_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(components_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_kinetic_energy(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], int rotational,
+                         double* out_dev, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!state || !out_dev) return fail(h, HYDRO_E_ARG, "null pointer");
+    KeArgs a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field"); a.st[f] = state[f]; }
+    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
+    a.mass = h->params + 10 * h->stride;
+    a.partials = h->ke_partials; a.out = out_dev; a.rotational = rotational; a.n = n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int blocks = grid_for(n > 0 ? n : 1, kBlock);
+    if (blocks > kKeBlocks) blocks = kKeBlocks;
+    hipLaunchKernelGGL(ke_partial_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(ke_final_kernel, dim3(1), dim3(kBlock), 0, s, h->ke_partials, blocks, out_dev);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STATE_FIELDS],
+                    const float* const wrench[HYDRO_WRENCH_FIELDS], float dt,
+                    float* const state_out[HYDRO_STATE_FIELDS], void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!state_in || !wrench || !state_out) return fail(h, HYDRO_E_ARG, "null pointer table");
+    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (n == 0) return HYDRO_OK;
+    IntArgs a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) {
+        if (!state_in[f] || !state_out[f]) return fail(h, HYDRO_E_ARG, "null state field");
+        a.si[f] = state_in[f]; a.so[f] = state_out[f];
+    }
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) { if (!wrench[f]) return fail(h, HYDRO_E_ARG, "null wrench field"); a.w[f] = wrench[f]; }
+    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
+    a.mass = h->params + 10 * h->stride;
+    a.g = h->g; a.dt = dt; a.n = n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (!(bodies_per_lane == 0 || bodies_per_lane == 1 || bodies_per_lane == 2 || bodies_per_lane == 4))
+        return fail(h, HYDRO_E_ARG, "bodies_per_lane must be 0, 1, 2 or 4");
+    if (!(block_threads == 0 || block_threads == kBlock)) return fail(h, HYDRO_E_ARG, "block_threads must be 0 or 256");
+    h->vec = bodies_per_lane;
+    return HYDRO_OK;
+}
+
+int hydro_sync(hydro_t* h)
+{
+    if (!h) return HYDRO_E_ARG;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+void* hydro_stream(hydro_t* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
+}  // extern "C"

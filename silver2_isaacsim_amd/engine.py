@@ -1,0 +1,203 @@
+"""Python host of the C ABI: one `HydroEngine` = one `hydro_t` handle on one GPU.
+
+PyTorch is used for plumbing only - device buffers, the current HIP stream and
+(in `distributed.py`) the process group.  Every numerical result comes from the
+hand-written HIP kernels in `csrc/hydro_kernels.hip` through `libhydro.so`;
+there is no CPU or eager-PyTorch fallback.
+
+Layouts: "SoA" tensors are contiguous `(F, N)` float32 device tensors - row f is
+field f (orders in include/hydro.h).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from ._native import HydroError
+
+
+def _as_soa_tensor(x, fields: int, device: torch.device) -> torch.Tensor:
+    """(N,F) or (F,N) array-like -> contiguous (F,N) float32 tensor on `device`."""
+    t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+    if t.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    if t.shape[0] != fields and t.shape[1] == fields:
+        t = t.t()
+    elif t.shape[0] != fields:
+        raise ValueError(f"expected {fields} fields, got shape {tuple(t.shape)}")
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HydroEngine:
+    """Batched replacement for N per-prim calculator objects of the reference
+    (`WarpHydrodynamicsWrapper`, warp_hydrodynamics_wrapper.py:5-132)."""
+
+    def __init__(self, capacity: int, device: int | str | torch.device = 0,
+                 water_density: float = 1025.0, gravity: float = 9.81):
+        self._lib = nat.load()                       # raises if the HIP extension is missing
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if dev.type != "cuda":
+            raise ValueError("HydroEngine runs on a GPU device only (no CPU path)")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else 0)
+        self.capacity = int(capacity)
+        self._h = ctypes.c_void_p()
+        rc = self._lib.hydro_create(self.device.index, self.capacity, ctypes.byref(self._h))
+        if rc != nat.HYDRO_OK:
+            self._h = None
+            raise HydroError(rc, f"hydro_create(device={self.device.index}, capacity={capacity}) failed")
+        self.n = 0
+        self.coeff_dtype = "f32"
+        self._tables: dict = {}
+        self.set_scene(water_density, gravity)
+
+    # ------------------------------------------------------------------ utils
+    def _check(self, rc: int) -> None:
+        if rc != nat.HYDRO_OK:
+            msg = self._lib.hydro_last_error(self._h)
+            raise HydroError(rc, msg.decode() if msg else "")
+
+    def _table(self, t: torch.Tensor, fields: int):
+        """Pointer table for a contiguous (fields, N) float32 device tensor (cached)."""
+        key = (t.data_ptr(), t.shape[1], fields)
+        tab = self._tables.get(key)
+        if tab is None:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape[0] != fields or t.device != self.device:
+                raise ValueError(f"expected contiguous float32 ({fields},N) tensor on {self.device}")
+            stride = t.shape[1] * 4
+            base = t.data_ptr()
+            tab = nat.pointer_table([base + f * stride for f in range(fields)])
+            if len(self._tables) > 256:
+                self._tables.clear()
+            self._tables[key] = tab
+        return tab
+
+    def _stream(self, stream) -> ctypes.c_void_p:
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(int(stream.cuda_stream if hasattr(stream, "cuda_stream") else stream))
+
+    # ------------------------------------------------------------ configuration
+    def set_scene(self, water_density: float, gravity: float) -> None:
+        self.water_density, self.gravity = float(water_density), float(gravity)
+        self._check(self._lib.hydro_set_scene(self._h, self.water_density, self.gravity))
+
+    def set_params(self, params, coeff_dtype: str = "f32") -> None:
+        """Per-body constants, (N,11) or (11,N): dims(3), cd_lin, cd_ang, damp_lin, damp_ang,
+        lift, am_lin, am_ang, mass.  coeff_dtype 'f16' stores the seven coefficients as half."""
+        t = _as_soa_tensor(params, nat.PARAM_FIELDS, self.device)
+        n = t.shape[1]
+        fn = {"f32": self._lib.hydro_set_params_f32, "f16": self._lib.hydro_set_params_f16}[coeff_dtype]
+        torch.cuda.current_stream(self.device).synchronize()      # the copy runs on the engine's stream
+        self._check(fn(self._h, n, self._table(t, nat.PARAM_FIELDS), 1))
+        self.n = n
+        self.coeff_dtype = coeff_dtype
+
+    def set_tuning(self, bodies_per_lane: int = 0, block_threads: int = 0) -> None:
+        self._check(self._lib.hydro_set_tuning(self._h, bodies_per_lane, block_threads))
+
+    # ------------------------------------------------- previous-velocity state
+    def reset_prev_velocity(self) -> None:
+        self._check(self._lib.hydro_reset_prev_velocity(self._h))
+
+    def get_prev_velocity(self) -> torch.Tensor:
+        out = torch.empty((nat.PREV_FIELDS, self.n), dtype=torch.float32, device=self.device)
+        self._check(self._lib.hydro_get_prev_velocity(self._h, self.n, self._table(out, nat.PREV_FIELDS), 1))
+        return out
+
+    def set_prev_velocity(self, prev) -> None:
+        t = _as_soa_tensor(prev, nat.PREV_FIELDS, self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.hydro_set_prev_velocity(self._h, t.shape[1], self._table(t, nat.PREV_FIELDS), 1))
+
+    # ----------------------------------------------------------------- hot path
+    def step_wrench(self, state: torch.Tensor, dt: float, out: torch.Tensor | None = None,
+                    prev: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """Fused wrench for state (13,N) -> out (6,N) [F|T].  With `prev` (6,N) the caller owns
+        the previous velocity (buffer-swap mode, nothing else is written); without it the
+        engine's own previous-velocity buffer is read and updated."""
+        n = state.shape[1]
+        if out is None:
+            out = torch.empty((nat.WRENCH_FIELDS, n), dtype=torch.float32, device=self.device)
+        st, ot = self._table(state, nat.STATE_FIELDS), self._table(out, nat.WRENCH_FIELDS)
+        if prev is None:
+            rc = self._lib.hydro_step_wrench(self._h, n, st, float(dt), ot, self._stream(stream))
+        else:
+            rc = self._lib.hydro_step_wrench_ext(self._h, n, st, self._table(prev, nat.PREV_FIELDS),
+                                                 float(dt), ot, self._stream(stream))
+        self._check(rc)
+        return out
+
+    def step_wrench_aos(self, positions: torch.Tensor, orientations_wxyz: torch.Tensor, velocities: torch.Tensor,
+                        dt: float, forces: torch.Tensor | None = None, torques: torch.Tensor | None = None,
+                        stream=None):
+        """Fused wrench on the simulator's tensors: positions (N,3), orientations (N,4) WXYZ,
+        velocities (N,6) -> forces (N,3), torques (N,3)."""
+        n = positions.shape[0]
+        for t, w in ((positions, 3), (orientations_wxyz, 4), (velocities, 6)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, w) or t.device != self.device:
+                raise ValueError(f"expected contiguous float32 ({n},{w}) tensor on {self.device}")
+        if forces is None:
+            forces = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        if torques is None:
+            torques = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        self._check(self._lib.hydro_step_wrench_aos(
+            self._h, n, positions.data_ptr(), orientations_wxyz.data_ptr(), velocities.data_ptr(), float(dt),
+            forces.data_ptr(), torques.data_ptr(), self._stream(stream)))
+        return forces, torques
+
+    def step_components(self, state: torch.Tensor, accel: torch.Tensor, out: torch.Tensor | None = None,
+                        ratio: torch.Tensor | None = None, stream=None):
+        """Component mode: state (13,N), accel (6,N) -> comps (24,N), ratio (N,)."""
+        n = state.shape[1]
+        if out is None:
+            out = torch.empty((nat.COMP_FIELDS, n), dtype=torch.float32, device=self.device)
+        if ratio is None:
+            ratio = torch.empty((n,), dtype=torch.float32, device=self.device)
+        self._check(self._lib.hydro_step_components(
+            self._h, n, self._table(state, nat.STATE_FIELDS), self._table(accel, nat.PREV_FIELDS),
+            self._table(out, nat.COMP_FIELDS), ratio.data_ptr(), self._stream(stream)))
+        return out, ratio
+
+    def kinetic_energy(self, state: torch.Tensor, rotational: bool = False, out: torch.Tensor | None = None,
+                       stream=None) -> torch.Tensor:
+        """[sum 1/2 m v^2, sum 1/2 w.I.w] as a float64 device tensor of shape (2,)."""
+        if out is None:
+            out = torch.empty((2,), dtype=torch.float64, device=self.device)
+        self._check(self._lib.hydro_kinetic_energy(self._h, state.shape[1], self._table(state, nat.STATE_FIELDS),
+                                                   int(bool(rotational)), out.data_ptr(), self._stream(stream)))
+        return out
+
+    def integrate(self, state_in: torch.Tensor, wrench: torch.Tensor, dt: float,
+                  state_out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        if state_out is None:
+            state_out = torch.empty_like(state_in)
+        self._check(self._lib.hydro_integrate(
+            self._h, state_in.shape[1], self._table(state_in, nat.STATE_FIELDS), self._table(wrench, nat.WRENCH_FIELDS),
+            float(dt), self._table(state_out, nat.STATE_FIELDS), self._stream(stream)))
+        return state_out
+
+    # ----------------------------------------------------------------- lifetime
+    def sync(self) -> None:
+        self._check(self._lib.hydro_sync(self._h))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.hydro_destroy(self._h)
+            self._h = None
+            self._tables.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

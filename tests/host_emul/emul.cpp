@@ -1,0 +1,26 @@
+// TEST-ONLY host instantiation of csrc/hydro_body.h: lets the CPU test-suite study
+// the fp32 arithmetic of the GPU kernels against the fp64 oracle without a GPU.
+// Not part of the product: nothing under silver2_isaacsim_amd/ builds or loads it.
+#include <stdint.h>
+#include "../../silver2_isaacsim_amd/csrc/hydro_body.h"
+
+extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, const float* params,
+                           float rho, float g, float inv_dt, float* net_f, float* net_t, float* ratio)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float* s = state + 13 * i; const float* pv = prev + 6 * i; const float* pr = params + 11 * i;
+        hydro::BodyIn b;
+        b.px = s[0]; b.py = s[1]; b.pz = s[2]; b.qx = s[3]; b.qy = s[4]; b.qz = s[5]; b.qw = s[6];
+        b.vx = s[7]; b.vy = s[8]; b.vz = s[9]; b.wx = s[10]; b.wy = s[11]; b.wz = s[12];
+        b.ax = (b.vx - pv[0]) * inv_dt; b.ay = (b.vy - pv[1]) * inv_dt; b.az = (b.vz - pv[2]) * inv_dt;
+        b.bx = (b.wx - pv[3]) * inv_dt; b.by = (b.wy - pv[4]) * inv_dt; b.bz = (b.wz - pv[5]) * inv_dt;
+        b.dimx = pr[0]; b.dimy = pr[1]; b.dimz = pr[2]; b.cd_lin = pr[3]; b.cd_ang = pr[4];
+        b.damp_lin = pr[5]; b.damp_ang = pr[6]; b.lift = pr[7]; b.am_lin = pr[8]; b.am_ang = pr[9];
+        const hydro::BodyOut o = hydro::solve_body(b, rho, g);
+        const hydro::Wrench w = hydro::assemble_wrench(o, pr[10]);
+        net_f[3 * i] = w.fx; net_f[3 * i + 1] = w.fy; net_f[3 * i + 2] = w.fz;
+        net_t[3 * i] = w.tx; net_t[3 * i + 1] = w.ty; net_t[3 * i + 2] = w.tz;
+        ratio[i] = o.ratio;
+    }
+    return 0;
+}
