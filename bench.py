@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused hydrodynamic-wrench step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one launch of `hydro_step_wrench_ext` over every body of one scene
+replica on this rank's GPU: finite-difference acceleration + nine-component
+model + lever arms + sum + clamp.  Inputs are resident in HBM
+before the timed region.  Bodies shard embarrassingly: every rank owns its own
+replica(s) of the workload (weak scaling), there is no data-path collective;
+the one RCCL call is the global kinetic-energy all-reduce after the timed loop.
+
+Workload (default `c5` = BASELINE.json configs[4], the configuration the
+"% of HBM roofline" part of the metric is quoted on): 1 048 576 synthetic bodies
+per GPU, 7 coefficients stored fp16, fp32 arithmetic, 130 algorithmic bytes per
+body-step.  `--scenes` (default 4) independent scene replicas are stepped
+round-robin so that the bytes touched between two uses of any line exceed the
+256 MiB Infinity Cache (cache caveat): the rate is an HBM rate.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from silver2_isaacsim_amd import distributed as hd          # noqa: E402
+from silver2_isaacsim_amd import scenes                     # noqa: E402
+from silver2_isaacsim_amd.engine import HydroEngine         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_CEILING_GBS = 6290.0    # measured float4-copy ceiling, same guide
+BYTES_PER_BODY = {"f32": 144, "f16": 130}    # SURVEY.md 8d / BASELINE.md 3
+
+WORKLOADS = {
+    # name: (scene builder kwargs, coefficient dtype, description)
+    "c5": ("c5", 1048576, "f16", "C5: 1 048 576 bodies/GPU, fp16 coefficients, fp32 arithmetic"),
+    "c5-f32": ("c4", 1048576, "f32", "C5 population with fp32 coefficients (144 B/body-step)"),
+    "c4": ("c4", 262144, "f32", "C4: 262 144 bodies (per GPU under weak scaling)"),
+    "c3": ("c3", 19456, "f32", "C3: SILVER2 hexapod x 1024 envs"),
+    "c2": ("c2", 4096, "f32", "C2: 4 096 buoys"),
+}
+
+
+def build_scene(kind: str, n: int, seed: int):
+    if kind == "c2":
+        return scenes.scene_c2(n=n, seed=seed)
+    if kind == "c3":
+        return scenes.scene_c3(envs=n // len(scenes.C3_LINKS), seed=seed)
+    # the margin-gated generator costs ~15 s per million bodies: draw 256k and tile
+    base_n = min(n, 262144)
+    sc = scenes.scene_c5(n=base_n, seed=seed) if kind == "c5" else scenes.scene_c4(n=base_n, seed=seed)
+    if base_n < n:
+        reps = (n + base_n - 1) // base_n
+        rng = np.random.default_rng(seed + 1000)
+        parts_s, parts_p, parts_q = [], [], []
+        for _ in range(reps):
+            perm = rng.permutation(base_n)
+            parts_s.append(sc.state[perm]); parts_p.append(sc.prev[perm]); parts_q.append(sc.params[perm])
+        sc = scenes.Scene(sc.name, np.concatenate(parts_s)[:n], np.concatenate(parts_p)[:n],
+                          np.concatenate(parts_q)[:n], sc.rho, sc.g, sc.dt, sc.coeff_dtype, dict(sc.info, tiled=reps))
+    return sc
+
+
+class Replica:
+    """One scene replica resident on the GPU: state, previous velocity, engine (params), output."""
+
+    def __init__(self, sc, coeff: str, dev, roll: int):
+        idx = np.roll(np.arange(sc.n), roll)
+        self.n = sc.n
+        self.dt = sc.dt
+        self.state = torch.from_numpy(scenes.to_soa(sc.state[idx])).to(dev)
+        self.prev = torch.from_numpy(scenes.to_soa(sc.prev[idx])).to(dev)
+        self.out = torch.empty((6, sc.n), dtype=torch.float32, device=dev)
+        self.engine = HydroEngine(sc.n, dev, sc.rho, sc.g)
+        self.engine.set_params(sc.params[idx], coeff)
+        self.index = idx
+
+    def step(self):
+        self.engine.step_wrench(self.state, self.dt, out=self.out, prev=self.prev)
+
+
+def timed_steps(replicas, steps: int, warmup: int, stream, world: int):
+    """W warm-up steps, then exactly K steps between barrier+synchronize pairs.  Returns
+    (wall seconds max over ranks, HIP-event milliseconds on the launch stream)."""
+    dev = replicas[0].state.device
+    with torch.cuda.stream(stream):
+        for k in range(warmup):
+            replicas[k % len(replicas)].step()
+    torch.cuda.synchronize(dev)
+    hd.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+        for k in range(steps):
+            replicas[k % len(replicas)].step()
+        ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    hd.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall], dtype=torch.float64, device=dev if world > 1 else "cpu")
+    hd.all_reduce_max_(t)
+    return float(t.item()), float(ev0.elapsed_time(ev1))
+
+
+def cpu_baseline_leg(sc, replica, budget_s: float):
+    """The C oracle (oracle/hydro_oracle.c, a port of the reference's Numba path) timed on this
+    box's host cores on a bounded sample of the same workload, and used as the checker of the
+    GPU result for that sample.  Only this function touches oracle/."""
+    from oracle import c_oracle, hydro_oracle
+    m = min(sc.n, 262144)
+    idx = replica.index[:m]
+    st, pv, pr = sc.state[idx], sc.prev[idx], sc.params[idx]
+    c_oracle.wrench(st[:1024], pv[:1024], pr[:1024], sc.rho, sc.g, sc.dt)          # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        ref_f, ref_t = c_oracle.wrench(st, pv, pr, sc.rho, sc.g, sc.dt, threads=1)
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    single = m * reps / (time.perf_counter() - t0)
+    threads = c_oracle.max_threads()
+    c_oracle.wrench(st, pv, pr, sc.rho, sc.g, sc.dt, threads=threads)               # spin the pool up
+    reps_mt, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.wrench(st, pv, pr, sc.rho, sc.g, sc.dt, threads=threads)
+        reps_mt += 1
+        if time.perf_counter() - t0 >= budget_s / 3:
+            break
+    multi = m * reps_mt / (time.perf_counter() - t0)
+    gpu = replica.out[:, :m].cpu().numpy().T
+    err = hydro_oracle.wrench_error(gpu[:, :3], gpu[:, 3:], ref_f, ref_t, pr, sc.rho, sc.g)
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
+    return {
+        "value": single, "unit": "body-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{m} bodies of the bench scene x {reps} passes, fp64 C port of the Numba path "
+                  f"(oracle/hydro_oracle.c, gcc -O3 -ffast-math), 1 thread",
+        "all_core_value": multi, "all_cores": threads, "cpu_model": cpu_model,
+        "gpu_vs_oracle_max_rel_err": float(err.max()), "gpu_vs_oracle_n_over_1e-5": int((err > 1e-5).sum()),
+        "gpu_vs_oracle_checked": int(m),
+    }
+
+
+def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets: int = 4, seed: int = 11):
+    """Small untimed-contract measurement for the 'extras' block (not the headline)."""
+    sc = build_scene(kind, n, seed)
+    reps = [Replica(sc, coeff, dev, roll=r * 97) for r in range(sets)]
+    _, ms = timed_steps(reps, steps, 10, stream, 1)
+    for r in reps:
+        r.engine.close()
+    us = ms * 1e3 / steps
+    return {"n": sc.n, "coeff": coeff, "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
+            "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
+
+
+def load_traffic(workload: str):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected
+    separately; FETCH_SIZE doubled per the gfx950 correction).  None when not measured."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(workload)
+        return rec
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--bodies", type=int, default=0, help="bodies per GPU (default: the workload's)")
+    ap.add_argument("--scenes", type=int, default=4, help="scene replicas stepped round-robin per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--bodies-per-lane", type=int, default=0)
+    args = ap.parse_args()
+
+    rank, local_rank, world = hd.env_rank_world()
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    hd.init_process_group()
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    kind, n_default, coeff, desc = WORKLOADS[args.workload]
+    n = args.bodies or n_default
+    sc = build_scene(kind, n, seed=5 + rank)
+    replicas = [Replica(sc, coeff, dev, roll=r * 131071) for r in range(args.scenes)]
+    if args.bodies_per_lane:
+        for r in replicas:
+            r.engine.set_tuning(args.bodies_per_lane)
+    stream = torch.cuda.Stream(dev)
+
+    wall, ev_ms = timed_steps(replicas, args.steps, args.warmup, stream, world)
+    body_steps = sc.n * args.steps * world
+    value = body_steps / wall
+    kernel_us = ev_ms * 1e3 / args.steps
+    bpb = BYTES_PER_BODY[coeff]
+    achieved = sc.n * bpb / (kernel_us * 1e-6) / 1e9
+
+    # the one collective of the path: global kinetic energy (every rank reduces its shard on device)
+    with torch.cuda.stream(stream):
+        ke = replicas[0].engine.kinetic_energy(replicas[0].state, rotational=True)
+    stream.synchronize()
+    t0 = time.perf_counter()
+    hd.global_kinetic_energy(ke)
+    torch.cuda.synchronize(dev)
+    ke_us = (time.perf_counter() - t0) * 1e6
+
+    if rank == 0:
+        traffic = load_traffic(args.workload) if world == 1 and not args.bodies else None
+        out = {
+            "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "bodies_per_gpu": sc.n, "coefficients": coeff,
+                       "scene_replicas_per_gpu": args.scenes, "bytes_per_body_step": bpb,
+                       "sharding": f"bodies x{world} (no data-path collective)",
+                       "entry_point": "hydro_step_wrench_ext"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                         "kernel": "wrench_soa_kernel", "kernel_us": kernel_us,
+                         "algorithmic_bytes_per_launch": sc.n * bpb,
+                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS},
+            "global_kinetic_energy_J": [float(x) for x in ke.cpu().tolist()],
+            "ke_allreduce_us": ke_us,
+        }
+        if traffic:
+            out["roofline"]["traffic_source"] = traffic.get("source")
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline_leg(sc, _last_stepped(replicas, args.steps), args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            for r in replicas:
+                r.engine.close()
+            replicas = []
+            torch.cuda.empty_cache()
+            ex = {}
+            ex["c2_4096"] = quick_rate("c2", 4096, "f32", dev, stream, steps=200)
+            ex["c3_19456"] = quick_rate("c3", 19456, "f32", dev, stream, steps=200)
+            ex["c4_shard_32768"] = quick_rate("c4", 32768, "f32", dev, stream, steps=200)
+            ex["c4_262144"] = quick_rate("c4", 262144, "f32", dev, stream, steps=100)
+            ex["c5_f32_1048576"] = quick_rate("c4", 1048576, "f32", dev, stream, steps=100)
+            ex["f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2)
+            out["extras"] = ex
+        print(json.dumps(out), flush=True)
+
+    hd.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def _last_stepped(replicas, steps):
+    """Replica whose output buffer holds the result of a completed step."""
+    return replicas[(steps - 1) % len(replicas)] if steps > 0 else replicas[0]
+
+
+if __name__ == "__main__":
+    main()

@@ -105,9 +105,11 @@ int hydro_step_wrench_ext(hydro_t *h, int64_t n, const float *const state[HYDRO_
 /* Same step on the array-of-structs tensors the simulator hands over
  * (RigidPrimView.get_world_poses / get_velocities, hydrodynamics_behavior.py:178-189) and takes
  * back (apply_forces_and_torques_at_pos, :229-234): positions (n,3), orientations (n,4) in the
- * simulator's WXYZ order (the reorder of :194 is done in the load), velocities (n,6) [lin|ang];
- * forces (n,3), torques (n,3).  Transposition is staged through LDS. */
-int hydro_step_wrench_aos(hydro_t *h, int64_t n, const float *positions, const float *orientations_wxyz,
+ * simulator's WXYZ order when quat_xyzw == 0 (the reorder of :194 is done in the load) or in the
+ * calculators' XYZW order when quat_xyzw != 0, velocities (n,6) [lin|ang]; forces (n,3),
+ * torques (n,3).  All five tensors 16-byte aligned.  Transposition is staged through LDS.
+ * Previous velocity lives in the engine, as for hydro_step_wrench. */
+int hydro_step_wrench_aos(hydro_t *h, int64_t n, const float *positions, const float *orientations, int quat_xyzw,
                           const float *velocities, float dt, float *forces, float *torques, void *stream);
 
 /* Component mode = WarpHydrodynamicsWrapper.calculate_hydrodynamic_forces

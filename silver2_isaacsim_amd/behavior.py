@@ -1,0 +1,362 @@
+"""`HydrodynamicsBehavior`: the reference's physics-step plugin on the HIP engine.
+
+Mirrors `HydrodynamicsBehavior(BehaviorScript)` of the reference
+(src/scripts/physics/hydrodynamics_behavior.py:21-249): same class name,
+`BEHAVIOR_NS`, `VARIABLES_TO_EXPOSE` (12 float attributes, same defaults), same
+lifecycle (`on_init / on_play / on_stop / on_destroy / _on_physics_step`), same
+JSON override rule, same error behaviour (state-fetch failures skip the step,
+:191-192; a prim without RigidBodyAPI gets a warning and no view, :144-146).
+
+What changes is underneath.  The reference creates one calculator and one
+`RigidPrimView` of size 1 per prim and pays ~40 GPU launches per prim per step
+(SURVEY.md 3.2).  Here every instance registers its prim with a process-wide
+`EngineRegistry`; the first physics-step callback of a step fetches the poses
+and velocities of ALL registered prims through one batched view, runs ONE fused
+kernel (`hydro_step_wrench_aos`: quaternion reorder, finite-difference
+acceleration, nine-component model, lever arms, sum, clamp) and applies all
+wrenches with one call; the other callbacks of that step return immediately.
+`batched=False` keeps the reference's one-view-per-prim flow (still one fused
+launch per prim instead of ~40).
+
+The simulator is reached only through the small `SimHost` protocol below, so
+the class runs under Kit (`KitHost`, imports omni/pxr lazily) and under the
+in-memory host of `silver2_isaacsim_amd.testing` alike.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Callable, Protocol, Sequence
+
+import numpy as np
+import torch
+
+from . import config as cfg
+from .engine import HydroEngine
+
+log = logging.getLogger("silver2_isaacsim_amd")
+
+_STATE_FETCH_ERRORS = (UnboundLocalError, IndexError, RuntimeError, AttributeError)   # :191
+
+
+class BodyView(Protocol):
+    """The six `RigidPrimView` methods the plugin uses (hydrodynamics_behavior.py:139,149-153,
+    172,178-179,229-234).  Tensors are torch, on the simulation device."""
+
+    def initialize(self) -> None: ...
+    def is_valid(self) -> bool: ...
+    def get_world_poses(self, clone: bool = False): ...          # (N,3), (N,4) wxyz
+    def get_velocities(self, clone: bool = False): ...           # (N,6) [lin | ang]
+    def get_masses(self, clone: bool = False): ...               # (N,)
+    def apply_forces_and_torques_at_pos(self, forces=None, torques=None, positions=None, is_global=True): ...
+
+
+class SimHost(Protocol):
+    """Everything the plugin needs from the simulator besides the body view."""
+
+    device: str
+    def create_exposed_variables(self, prim, variables: Sequence[dict]) -> None: ...
+    def remove_exposed_variables(self, prim, variables: Sequence[dict]) -> None: ...
+    def get_exposed_variable(self, prim, full_attr_name: str) -> float: ...
+    def set_exposed_variable(self, prim, full_attr_name: str, value: float) -> bool: ...
+    def has_rigid_body_api(self, prim) -> bool: ...
+    def prim_path(self, prim) -> str: ...
+    def make_rigid_view(self, prim_paths: Sequence[str], name: str) -> BodyView: ...
+    def subscribe_physics_step(self, callback: Callable[[float], None]) -> Any: ...
+    def config_path(self) -> str | None: ...
+
+
+# --------------------------------------------------------------------------
+# batching registry
+# --------------------------------------------------------------------------
+class _Group:
+    """All registered prims that share one host and one (water density, gravity) pair."""
+
+    def __init__(self, host: SimHost, rho: float, g: float):
+        self.host, self.rho, self.g = host, rho, g
+        self.members: list["HydrodynamicsBehavior"] = []
+        self.pending: set[int] = set()
+        self.view: BodyView | None = None
+        self.engine: HydroEngine | None = None
+        self.dirty = True
+        self.steps = 0
+        self.force = self.torque = None
+
+    def rebuild(self) -> None:
+        if self.engine is not None:
+            self.engine.close()
+        paths = [m._prim_path for m in self.members]
+        self.view = self.host.make_rigid_view(paths, "hydro_view_batched")
+        self.view.initialize()
+        masses = self.view.get_masses(clone=False)
+        masses = masses.detach().to("cpu", torch.float32).numpy().reshape(-1)
+        rows = np.stack([m._param_row(masses[i]) for i, m in enumerate(self.members)], axis=0)
+        self.engine = HydroEngine(len(paths), self.host.device, self.rho, self.g)
+        self.engine.set_params(rows)
+        n = len(paths)
+        self.force = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
+        self.torque = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
+        self.dirty = False
+
+    def step(self, dt: float) -> None:
+        if self.dirty:
+            self.rebuild()
+        if self.view is None or not self.view.is_valid():
+            return
+        try:
+            positions, orientations = self.view.get_world_poses(clone=False)
+            velocities = self.view.get_velocities(clone=False)
+            if velocities is None or velocities.shape[0] == 0:
+                return
+            dev = self.engine.device
+            positions = positions.to(dev).contiguous()
+            orientations = orientations.to(dev).contiguous()
+            velocities = velocities.to(dev).contiguous()
+        except _STATE_FETCH_ERRORS:
+            return
+        self.engine.step_wrench_aos(positions, orientations, velocities, dt, forces=self.force, torques=self.torque)
+        self.view.apply_forces_and_torques_at_pos(forces=self.force, torques=self.torque,
+                                                  positions=positions, is_global=True)
+        self.steps += 1
+
+    def close(self) -> None:
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = self.view = None
+
+
+class EngineRegistry:
+    """Process-wide: N per-prim callbacks per physics step -> one kernel launch."""
+
+    def __init__(self):
+        self._groups: dict[tuple, _Group] = {}
+
+    def register(self, b: "HydrodynamicsBehavior") -> _Group:
+        key = (id(b._host), float(b._rho), float(b._g))
+        grp = self._groups.get(key)
+        if grp is None:
+            grp = self._groups[key] = _Group(b._host, b._rho, b._g)
+        grp.members.append(b)
+        grp.dirty = True
+        grp.pending.clear()
+        return grp
+
+    def unregister(self, b: "HydrodynamicsBehavior") -> None:
+        for key, grp in list(self._groups.items()):
+            if b in grp.members:
+                grp.members.remove(b)
+                grp.dirty = True
+                grp.pending.clear()
+                if not grp.members:
+                    grp.close()
+                    del self._groups[key]
+
+    @staticmethod
+    def on_step(grp: _Group, b: "HydrodynamicsBehavior", dt: float) -> None:
+        """Called once per member per physics step.  The first caller of a step runs the batch."""
+        key = id(b)
+        if key in grp.pending:
+            grp.pending.discard(key)
+            return
+        grp.step(dt)
+        grp.pending = {id(m) for m in grp.members if m is not b}
+
+    def clear(self) -> None:
+        for grp in self._groups.values():
+            grp.close()
+        self._groups.clear()
+
+
+REGISTRY = EngineRegistry()
+
+
+# --------------------------------------------------------------------------
+# the plugin
+# --------------------------------------------------------------------------
+class HydrodynamicsBehavior:
+    """Drop-in counterpart of the reference's behavior script.  Under Kit, derive the
+    scripted class from both this and `omni.kit.scripting.BehaviorScript`;
+    `prim` / `prim_path` are then provided by Kit and `host` defaults to `KitHost()`."""
+
+    BEHAVIOR_NS = cfg.BEHAVIOR_NS
+    VARIABLES_TO_EXPOSE = cfg.variables_to_expose()
+
+    def __init__(self, prim=None, host: SimHost | None = None, batched: bool = True):
+        if prim is not None:
+            self.prim = prim
+        self._host = host
+        self._batched = batched
+        self._group: _Group | None = None
+        self._engine: HydroEngine | None = None
+
+    # -- lifecycle -----------------------------------------------------------
+    def on_init(self):
+        if self._host is None:
+            self._host = KitHost()
+        self._device = self._host.device
+        self._hydro_calculator = None
+        self._rigid_prim_view = None
+        self._physx_subscription = None
+        self._prim_path = self._host.prim_path(self.prim)
+        self._host.create_exposed_variables(self.prim, self.VARIABLES_TO_EXPOSE)
+        self._apply_json_config()
+
+    def _apply_json_config(self):
+        """globals, then the first `parts` key contained in the lower-cased prim name
+        (hydrodynamics_behavior.py:72-112)."""
+        path = self._host.config_path()
+        try:
+            data = cfg.load_config(path)
+            if data is None:
+                return
+            for name, value in cfg.resolve_overrides(self.prim.GetName(), data).items():
+                self._set_attr(name, value)
+        except Exception as e:                                    # noqa: BLE001 - reference swallows and logs (:111-112)
+            log.error("[Hydro] JSON Error: %s", e)
+
+    def _set_attr(self, name, value):
+        if not self._host.set_exposed_variable(self.prim, cfg.full_attr_name(name), float(value)):
+            log.warning("[Hydro] Failed to set attribute: %s", cfg.full_attr_name(name))
+
+    def on_destroy(self):
+        self._reset()
+        self._host.remove_exposed_variables(self.prim, self.VARIABLES_TO_EXPOSE)
+
+    def on_play(self):
+        self._setup()
+        self._physx_subscription = self._host.subscribe_physics_step(self._on_physics_step)
+
+    def on_stop(self):
+        self._reset()
+
+    # FixedUpdate
+    def _on_physics_step(self, delta_time: float):
+        if delta_time <= 1e-6:
+            return
+        if self._batched:
+            if self._group is not None:
+                EngineRegistry.on_step(self._group, self, delta_time)
+            return
+        if self._rigid_prim_view is None or not self._rigid_prim_view.is_valid():
+            return
+        self._apply_behavior(delta_time)
+
+    def _get_exposed_variable(self, attr_name):
+        return self._host.get_exposed_variable(self.prim, cfg.full_attr_name(attr_name))
+
+    def _param_row(self, mass: float) -> np.ndarray:
+        g = self._get_exposed_variable
+        return np.array([g("xDimension"), g("yDimension"), g("zDimension"),
+                         g("linearDragCoefficient"), g("angularDragCoefficient"),
+                         g("linearDamping"), g("angularDamping"), g("liftCoefficient"),
+                         g("linearAddedMassCoefficient"), g("angularAddedMassCoefficient"), mass], dtype=np.float32)
+
+    def _setup(self):
+        if not self._host.has_rigid_body_api(self.prim):
+            log.warning("HydrodynamicsBehavior on prim %s requires a RigidBody component.", self._prim_path)
+            return
+        self._rho = self._get_exposed_variable("waterDensity")
+        self._g = self._get_exposed_variable("gravity")
+        if self._batched:
+            self._group = REGISTRY.register(self)
+            return
+        name = self._prim_path.rsplit("/", 1)[-1]
+        self._rigid_prim_view = self._host.make_rigid_view([self._prim_path], f"hydro_view_{name}")
+        self._rigid_prim_view.initialize()
+        masses = self._rigid_prim_view.get_masses(clone=False)
+        self._mass = float(masses[0])
+        self._engine = HydroEngine(1, self._device, self._rho, self._g)
+        self._engine.set_params(self._param_row(self._mass)[None, :])
+        self._hydro_calculator = self._engine
+        self._force = torch.empty((1, 3), dtype=torch.float32, device=self._engine.device)
+        self._torque = torch.empty((1, 3), dtype=torch.float32, device=self._engine.device)
+        log.info("HydrodynamicsBehavior (HIP) initialized for %s", self._prim_path)
+
+    def _apply_behavior(self, delta_time):
+        try:
+            positions, orientations = self._rigid_prim_view.get_world_poses(clone=False)
+            full_velocities = self._rigid_prim_view.get_velocities(clone=False)
+            if full_velocities is None or full_velocities.shape[0] == 0:
+                return
+            dev = self._engine.device
+            positions = positions.to(dev).contiguous()
+            orientations = orientations.to(dev).contiguous()
+            full_velocities = full_velocities.to(dev).contiguous()
+        except _STATE_FETCH_ERRORS:
+            return
+        # quaternion reorder, finite-difference acceleration, model, lever arms, sum and clamp
+        # (hydrodynamics_behavior.py:194-226) are one kernel; the previous velocity lives in the engine
+        self._engine.step_wrench_aos(positions, orientations, full_velocities, delta_time,
+                                     forces=self._force, torques=self._torque)
+        self._rigid_prim_view.apply_forces_and_torques_at_pos(
+            forces=self._force, torques=self._torque, positions=positions, is_global=True)
+
+    def _reset(self):
+        if self._group is not None:
+            REGISTRY.unregister(self)
+            self._group = None
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        self._hydro_calculator = None
+        self._rigid_prim_view = None
+        self._physx_subscription = None
+
+
+# --------------------------------------------------------------------------
+# Kit host (only importable inside Isaac Sim; nothing here runs on an AMD box)
+# --------------------------------------------------------------------------
+class KitHost:
+    """Binds the `SimHost` protocol to Omniverse Kit / Isaac Sim.  Imports are lazy so
+    that this module loads without `omni`, `pxr`, `carb` (none exist outside Kit)."""
+
+    def __init__(self, device: str = "cuda:0", config_dir: str | None = None):
+        self.device = device
+        self._config_dir = config_dir or os.path.dirname(os.path.abspath(__file__))
+
+    def _utils(self):
+        from isaacsim.replicator.behavior.utils import behavior_utils    # type: ignore
+        return behavior_utils
+
+    def create_exposed_variables(self, prim, variables):
+        from pxr import Sdf                                               # type: ignore
+        typed = [dict(v, attr_type=Sdf.ValueTypeNames.Float) for v in variables]
+        self._utils().create_exposed_variables(prim, cfg.EXPOSED_ATTR_NS, cfg.BEHAVIOR_NS, typed)
+
+    def remove_exposed_variables(self, prim, variables):
+        from pxr import Sdf                                               # type: ignore
+        typed = [dict(v, attr_type=Sdf.ValueTypeNames.Float) for v in variables]
+        if self._utils().check_if_exposed_variables_should_be_removed(prim, __file__):
+            self._utils().remove_exposed_variables(prim, cfg.EXPOSED_ATTR_NS, cfg.BEHAVIOR_NS, typed)
+
+    def get_exposed_variable(self, prim, full_attr_name):
+        return self._utils().get_exposed_variable(prim, full_attr_name)
+
+    def set_exposed_variable(self, prim, full_attr_name, value):
+        attr = prim.GetAttribute(full_attr_name)
+        if attr and attr.IsValid():
+            attr.Set(float(value))
+            return True
+        return False
+
+    def has_rigid_body_api(self, prim):
+        from pxr import UsdPhysics                                        # type: ignore
+        return prim.HasAPI(UsdPhysics.RigidBodyAPI)
+
+    def prim_path(self, prim):
+        return str(prim.GetPath())
+
+    def make_rigid_view(self, prim_paths, name):
+        from omni.isaac.core.prims import RigidPrimView                   # type: ignore
+        expr = prim_paths[0] if len(prim_paths) == 1 else list(prim_paths)
+        return RigidPrimView(prim_paths_expr=expr, name=name)
+
+    def subscribe_physics_step(self, callback):
+        import omni.physx                                                 # type: ignore
+        return omni.physx.get_physx_interface().subscribe_physics_step_events(callback)
+
+    def config_path(self):
+        # a hydrodynamics_config.json beside the script wins (as in the reference, :76-77);
+        # without one the built-in table - the values the reference ships - is used
+        p = os.path.join(self._config_dir, cfg.CONFIG_FILE_NAME)
+        return p if os.path.exists(p) else None

@@ -34,37 +34,51 @@ template <> struct FVec<1> { using type = float; };
 template <> struct FVec<2> { using type = float2; };
 template <> struct FVec<4> { using type = float4; };
 
+// `i` is a 32-bit ELEMENT index; the byte offset is formed in 32 bits on purpose so that the
+// access compiles to the "SGPR base + 32-bit VGPR offset" addressing form (no 64-bit per-lane
+// address arithmetic, no VGPR pairs for addresses).  hydro_create caps capacity at 2^30.
+template <typename T>
+__device__ __forceinline__ const T* at(const void* __restrict__ p, uint32_t byte_off)
+{
+    return reinterpret_cast<const T*>(static_cast<const char*>(p) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ T* at(void* __restrict__ p, uint32_t byte_off)
+{
+    return reinterpret_cast<T*>(static_cast<char*>(p) + byte_off);
+}
+
 template <int VEC>
-__device__ __forceinline__ void load_f32(const float* __restrict__ p, int64_t i, float (&out)[VEC])
+__device__ __forceinline__ void load_f32(const float* __restrict__ p, uint32_t i, float (&out)[VEC])
 {
     using V = typename FVec<VEC>::type;
-    const V v = *reinterpret_cast<const V*>(p + i);
+    const V v = *at<V>(p, i * 4u);
     const float* f = reinterpret_cast<const float*>(&v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) out[j] = f[j];
 }
 
 template <int VEC>
-__device__ __forceinline__ void store_f32(float* __restrict__ p, int64_t i, const float (&in)[VEC])
+__device__ __forceinline__ void store_f32(float* __restrict__ p, uint32_t i, const float (&in)[VEC])
 {
     using V = typename FVec<VEC>::type;
     V v;
     float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) f[j] = in[j];
-    *reinterpret_cast<V*>(p + i) = v;
+    *at<V>(p, i * 4u) = v;
 }
 
 template <int VEC>
-__device__ __forceinline__ void load_f16(const __half* __restrict__ p, int64_t i, float (&out)[VEC])
+__device__ __forceinline__ void load_f16(const __half* __restrict__ p, uint32_t i, float (&out)[VEC])
 {
     if constexpr (VEC == 1) {
-        out[0] = __half2float(p[i]);
+        out[0] = __half2float(*at<__half>(p, i * 2u));
     } else if constexpr (VEC == 2) {
-        const __half2 h = *reinterpret_cast<const __half2*>(p + i);
+        const __half2 h = *at<__half2>(p, i * 2u);
         out[0] = __low2float(h); out[1] = __high2float(h);
     } else {
-        const uint2 raw = *reinterpret_cast<const uint2*>(p + i);
+        const uint2 raw = *at<uint2>(p, i * 2u);
         const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
         const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
         out[0] = __low2float(a); out[1] = __high2float(a); out[2] = __low2float(b); out[3] = __high2float(b);
@@ -72,18 +86,21 @@ __device__ __forceinline__ void load_f16(const __half* __restrict__ p, int64_t i
 }
 
 template <int VEC, bool HALF>
-__device__ __forceinline__ void load_coef(const void* __restrict__ p, int64_t i, float (&out)[VEC])
+__device__ __forceinline__ void load_coef(const void* __restrict__ p, uint32_t i, float (&out)[VEC])
 {
     if constexpr (HALF) load_f16<VEC>(static_cast<const __half*>(p), i, out);
     else load_f32<VEC>(static_cast<const float*>(p), i, out);
 }
 
 template <bool HALF>
-__device__ __forceinline__ float load_coef1(const void* __restrict__ p, int64_t i)
+__device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t i)
 {
-    if constexpr (HALF) return __half2float(static_cast<const __half*>(p)[i]);
-    else return static_cast<const float*>(p)[i];
+    if constexpr (HALF) return __half2float(*at<__half>(p, i * 2u));
+    else return *at<float>(p, i * 4u);
 }
+
+__device__ __forceinline__ float ld1(const float* __restrict__ p, uint32_t i) { return *at<float>(p, i * 4u); }
+__device__ __forceinline__ void st1(float* __restrict__ p, uint32_t i, float v) { *at<float>(p, i * 4u) = v; }
 
 // --------------------------------------------------------------------------
 // kernel arguments (passed by value in the kernarg segment: pointers land in SGPRs)
@@ -128,38 +145,23 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
 template <int VEC, bool HALF, bool WRITE_PREV>
 __global__ void __launch_bounds__(kBlock) wrench_soa_kernel(const SoaArgs a)
 {
-    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-    if (base >= a.n) return;
+    // Precondition (host side, launch_soa): a.n is a multiple of VEC; the <= VEC-1 leftover
+    // bodies go to a second launch of the VEC=1 instance.  32-bit element offsets: the field
+    // base pointers stay in SGPRs and every access is "saddr + 32-bit voffset".
+    const uint32_t n = (uint32_t)a.n;
+    const uint32_t base = (blockIdx.x * kBlock + threadIdx.x) * VEC;
+    if (base >= n) return;
 
     float st[HYDRO_STATE_FIELDS][VEC], pv[HYDRO_PREV_FIELDS][VEC], dm[3][VEC], cf[7][VEC], ms[VEC];
-    const bool full = (base + VEC <= a.n);
-    if (full) {
 #pragma unroll
-        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) load_f32<VEC>(a.st[f], base, st[f]);
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) load_f32<VEC>(a.st[f], base, st[f]);
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) load_f32<VEC>(a.pv[f], base, pv[f]);
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) load_f32<VEC>(a.pv[f], base, pv[f]);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) load_f32<VEC>(a.dims[f], base, dm[f]);
+    for (int f = 0; f < 3; ++f) load_f32<VEC>(a.dims[f], base, dm[f]);
 #pragma unroll
-        for (int f = 0; f < 7; ++f) load_coef<VEC, HALF>(a.coef[f], base, cf[f]);
-        load_f32<VEC>(a.mass, base, ms);
-    } else {
-        // ragged tail (only the last lane with work): element-wise, padded with a benign body
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const bool ok = base + j < a.n;
-            const int64_t i = ok ? base + j : base;
-#pragma unroll
-            for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) st[f][j] = a.st[f][i];
-#pragma unroll
-            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f][j] = a.pv[f][i];
-#pragma unroll
-            for (int f = 0; f < 3; ++f) dm[f][j] = a.dims[f][i];
-#pragma unroll
-            for (int f = 0; f < 7; ++f) cf[f][j] = load_coef1<HALF>(a.coef[f], i);
-            ms[j] = a.mass[i];
-        }
-    }
+    for (int f = 0; f < 7; ++f) load_coef<VEC, HALF>(a.coef[f], base, cf[f]);
+    load_f32<VEC>(a.mass, base, ms);
 
     float out[HYDRO_WRENCH_FIELDS][VEC];
 #pragma unroll
@@ -178,25 +180,11 @@ __global__ void __launch_bounds__(kBlock) wrench_soa_kernel(const SoaArgs a)
         out[3][j] = w.tx; out[4][j] = w.ty; out[5][j] = w.tz;
     }
 
-    if (full) {
 #pragma unroll
-        for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) store_f32<VEC>(a.out[f], base, out[f]);
-        if constexpr (WRITE_PREV) {
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) store_f32<VEC>(a.out[f], base, out[f]);
+    if constexpr (WRITE_PREV) {
 #pragma unroll
-            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) store_f32<VEC>(a.pv_out[f], base, st[7 + f]);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (base + j < a.n) {
-#pragma unroll
-                for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) a.out[f][base + j] = out[f][j];
-                if constexpr (WRITE_PREV) {
-#pragma unroll
-                    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv_out[f][base + j] = st[7 + f][j];
-                }
-            }
-        }
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) store_f32<VEC>(a.pv_out[f], base, st[7 + f]);
     }
 }
 
@@ -210,7 +198,8 @@ __global__ void __launch_bounds__(kBlock) wrench_soa_kernel(const SoaArgs a)
 // --------------------------------------------------------------------------
 struct AosArgs {
     const float* pos;       // (n,3)
-    const float* quat_wxyz; // (n,4)
+    const float* quat;      // (n,4)
+    int quat_xyzw;          // 0: simulator order w,x,y,z   1: kernel order x,y,z,w
     const float* vel;       // (n,6)
     float* force;           // (n,3)
     float* torque;          // (n,3)
@@ -251,8 +240,9 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
     const int tc = (int)(ic - block0);
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7];
     s[0] = lds_pos[3 * tc]; s[1] = lds_pos[3 * tc + 1]; s[2] = lds_pos[3 * tc + 2];
-    const float4 q = reinterpret_cast<const float4*>(a.quat_wxyz)[ic];   // w x y z
-    s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x;                      // -> x y z w  (hydrodynamics_behavior.py:194)
+    const float4 q = reinterpret_cast<const float4*>(a.quat)[ic];
+    if (a.quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
+    else             { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
 #pragma unroll
     for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * tc + f];
 #pragma unroll
@@ -533,11 +523,41 @@ void fill_params(hydro_engine* h, Args& a)
 }
 
 template <int VEC, bool WRITE_PREV>
-void launch_soa(hydro_engine* h, const SoaArgs& a, hipStream_t s)
+void launch_soa_n(hydro_engine* h, const SoaArgs& a, hipStream_t s)
 {
     const int grid = grid_for(a.n, kBlock * VEC);
     if (h->half_coeffs) hipLaunchKernelGGL((wrench_soa_kernel<VEC, true, WRITE_PREV>), dim3(grid), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((wrench_soa_kernel<VEC, false, WRITE_PREV>), dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+// args shifted by `off` bodies (for the ragged remainder of a vector launch)
+SoaArgs shifted(const SoaArgs& a, int64_t off, int64_t n, bool half)
+{
+    SoaArgs b = a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) b.st[f] = a.st[f] + off;
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) { b.pv[f] = a.pv[f] + off; b.pv_out[f] = a.pv_out[f] ? a.pv_out[f] + off : nullptr; }
+    for (int f = 0; f < 3; ++f) b.dims[f] = a.dims[f] + off;
+    for (int f = 0; f < 7; ++f)
+        b.coef[f] = half ? static_cast<const void*>(static_cast<const __half*>(a.coef[f]) + off)
+                         : static_cast<const void*>(static_cast<const float*>(a.coef[f]) + off);
+    b.mass = a.mass + off;
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) b.out[f] = a.out[f] + off;
+    b.n = n;
+    return b;
+}
+
+template <int VEC, bool WRITE_PREV>
+void launch_soa(hydro_engine* h, const SoaArgs& a, hipStream_t s)
+{
+    const int64_t n_vec = a.n / VEC * VEC;
+    if (n_vec > 0) {
+        SoaArgs b = a;
+        b.n = n_vec;
+        launch_soa_n<VEC, WRITE_PREV>(h, b, s);
+    }
+    if constexpr (VEC > 1) {
+        if (a.n > n_vec) launch_soa_n<1, WRITE_PREV>(h, shifted(a, n_vec, a.n - n_vec, h->half_coeffs), s);
+    }
 }
 
 template <bool WRITE_PREV>
@@ -550,7 +570,7 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
     if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if (n == 0) return HYDRO_OK;
     SoaArgs a;
-    int vec = h->vec ? h->vec : 2;
+    int vec = h->vec ? h->vec : 1;
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) {
         if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field");
         a.st[f] = state[f];
@@ -643,7 +663,7 @@ int hydro_device_count(int* count)
 
 int hydro_create(int device, int64_t capacity, hydro_t** out)
 {
-    if (!out || capacity <= 0) return HYDRO_E_ARG;
+    if (!out || capacity <= 0 || capacity > ((int64_t)1 << 30)) return HYDRO_E_ARG;
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HYDRO_E_DEVICE;
@@ -753,9 +773,10 @@ int hydro_step_wrench_ext(hydro_t* h, int64_t n, const float* const state[HYDRO_
     return step_soa<false>(h, n, state, prev, nullptr, dt, wrench, stream);
 }
 
-int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations_wxyz,
+int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,
                           const float* velocities, float dt, float* forces, float* torques, void* stream)
 {
+    const float* orientations_wxyz = orientations;
     int rc = check_common(h, n);
     if (rc) return rc;
     if (!positions || !orientations_wxyz || !velocities || !forces || !torques) return fail(h, HYDRO_E_ARG, "null tensor pointer");
@@ -765,7 +786,7 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
         return fail(h, HYDRO_E_ARG, "array-of-structs tensors must be 16-byte aligned");
     if (n == 0) return HYDRO_OK;
     AosArgs a;
-    a.pos = positions; a.quat_wxyz = orientations_wxyz; a.vel = velocities; a.force = forces; a.torque = torques;
+    a.pos = positions; a.quat = orientations; a.quat_xyzw = quat_xyzw ? 1 : 0; a.vel = velocities; a.force = forces; a.torque = torques;
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv[f] = h->prev + f * h->stride;
     fill_params(h, a);
     a.mass = h->params + 10 * h->stride;

@@ -130,13 +130,14 @@ class HydroEngine:
         self._check(rc)
         return out
 
-    def step_wrench_aos(self, positions: torch.Tensor, orientations_wxyz: torch.Tensor, velocities: torch.Tensor,
+    def step_wrench_aos(self, positions: torch.Tensor, orientations: torch.Tensor, velocities: torch.Tensor,
                         dt: float, forces: torch.Tensor | None = None, torques: torch.Tensor | None = None,
-                        stream=None):
-        """Fused wrench on the simulator's tensors: positions (N,3), orientations (N,4) WXYZ,
-        velocities (N,6) -> forces (N,3), torques (N,3)."""
+                        quat_xyzw: bool = False, stream=None):
+        """Fused wrench on the simulator's tensors: positions (N,3), orientations (N,4) (WXYZ as the
+        simulator gives them, or XYZW with quat_xyzw=True), velocities (N,6) -> forces (N,3),
+        torques (N,3).  Uses and updates the engine's previous-velocity state."""
         n = positions.shape[0]
-        for t, w in ((positions, 3), (orientations_wxyz, 4), (velocities, 6)):
+        for t, w in ((positions, 3), (orientations, 4), (velocities, 6)):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, w) or t.device != self.device:
                 raise ValueError(f"expected contiguous float32 ({n},{w}) tensor on {self.device}")
         if forces is None:
@@ -144,7 +145,7 @@ class HydroEngine:
         if torques is None:
             torques = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         self._check(self._lib.hydro_step_wrench_aos(
-            self._h, n, positions.data_ptr(), orientations_wxyz.data_ptr(), velocities.data_ptr(), float(dt),
+            self._h, n, positions.data_ptr(), orientations.data_ptr(), int(bool(quat_xyzw)), velocities.data_ptr(), float(dt),
             forces.data_ptr(), torques.data_ptr(), self._stream(stream)))
         return forces, torques
 

@@ -1,0 +1,337 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the fp64 oracle.
+
+Gate (north_star: "per-body wrench parity to the Numba reference within 1e-5 relative"):
+    max( |dF| / max(|F_ref|, 1e-3 rho g V),  |dT| / max(|T_ref|, 1e-3 rho g V L) ) <= 1e-5
+per body, on the golden fixtures (whose reference outputs came from the
+reference itself) and on seeded scenes.  At BASELINE's full sizes the oracle would be slow, so
+size-independent properties are used there (exact zeros for dry bodies, x/y translation
+invariance, sharded == unsharded bit for bit, yaw equivariance)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SCENE_FIXTURES, accel_of, load_golden
+from oracle import hydro_oracle as ho
+from silver2_isaacsim_amd import scenes
+from silver2_isaacsim_amd._native import HydroError
+from silver2_isaacsim_amd.engine import HydroEngine
+
+pytestmark = pytest.mark.gpu
+GATE = 1e-5
+DEV = "cuda:0"
+
+
+def soa(x):
+    return torch.from_numpy(scenes.to_soa(x)).to(DEV)
+
+
+def run_ext(state, prev, params, rho, g, dt, coeff="f32", vec=0):
+    eng = HydroEngine(len(state), DEV, rho, g)
+    eng.set_params(params, coeff)
+    eng.set_tuning(vec)
+    out = eng.step_wrench(soa(state), dt, prev=soa(prev))
+    torch.cuda.synchronize()
+    eng.close()
+    o = out.cpu().numpy().T
+    return o[:, :3], o[:, 3:]
+
+
+@pytest.mark.parametrize("name", SCENE_FIXTURES)
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_fused_wrench_matches_oracle_on_fixtures(name, vec, native_built):
+    fx = load_golden(name)
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    coeff = "f16" if name == "c5" else "f32"
+    f, t = run_ext(fx["state"], fx["prev"], fx["params"], rho, g, dt, coeff, vec)
+    rf, rt, aux = ho.step_wrench(fx["state"], fx["prev"], fx["params"], rho, g, dt)
+    err = ho.wrench_error(f, t, rf, rt, fx["params"], rho, g)
+    assert np.isfinite(f).all() and np.isfinite(t).all()
+    assert err.max() <= GATE, f"{name} vec={vec}: {err.max():.3e}"
+    dry = aux["ratio"] == 0.0
+    assert np.all(f[dry] == 0.0) and np.all(t[dry] == 0.0)
+
+
+@pytest.mark.parametrize("name,builder", [("C2", scenes.scene_c2), ("C3", scenes.scene_c3)])
+def test_full_config_gate(name, builder, native_built):
+    """Configs 2 and 3 in full (4 096 buoys; 19 x 1 024 hexapod links): gate 1e-5 on every body."""
+    sc = builder()
+    f, t = run_ext(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    rf, rt, _ = ho.step_wrench(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)
+    assert err.max() <= GATE
+
+
+def test_ungated_population_report(native_built):
+    """No branch-margin rule (adversarial set): reported, loosely gated."""
+    sc = scenes.scene_c4(n=131072, seed=4242, margin=None)
+    f, t = run_ext(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    rf, rt, _ = ho.step_wrench(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)
+    print(f"ungated 131072 bodies: max {err.max():.3e} p99.9 {np.percentile(err, 99.9):.3e} n>1e-5 {(err > GATE).sum()}")
+    assert np.percentile(err, 99.9) < 2e-6 and (err > GATE).sum() <= 3
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 257, 1000, 4095])
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_ragged_sizes(n, vec, native_built):
+    fx = load_golden("c4")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    st, pv, pr = fx["state"][:n], fx["prev"][:n], fx["params"][:n]
+    f, t = run_ext(st, pv, pr, rho, g, dt, vec=vec)
+    f1, t1 = run_ext(fx["state"], fx["prev"], fx["params"], rho, g, dt, vec=1)
+    assert np.array_equal(f, f1[:n]) and np.array_equal(t, t1[:n])          # same bits as the big launch
+
+
+def test_output_tail_is_not_touched(native_built):
+    """A launch over n bodies must not write past element n of any output field."""
+    fx = load_golden("c2")
+    n = 1001
+    eng = HydroEngine(2048, DEV, float(fx["rho"]), float(fx["g"]))
+    eng.set_params(fx["params"][:2048])
+    out = torch.full((6, 2048), -777.0, device=DEV)
+    S, P = soa(fx["state"][:2048]), soa(fx["prev"][:2048])
+    for vec in (1, 2, 4):
+        out.fill_(-777.0)
+        eng.set_tuning(vec)
+        lib_n = eng._lib.hydro_step_wrench_ext(eng._h, n, eng._table(S, 13), eng._table(P, 6), float(fx["dt"]),
+                                               eng._table(out, 6), eng._stream(None))
+        assert lib_n == 0
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.all(o[:, n:] == -777.0) and np.all(o[:, :n] != -777.0)
+    eng.close()
+
+
+def test_engine_owned_previous_velocity(native_built):
+    fx = load_golden("c4")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = len(fx["state"])
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(fx["params"])
+    S = soa(fx["state"])
+    # first step: previous velocity is zero (hydrodynamics_behavior.py:196-198)
+    out0 = eng.step_wrench(S, dt).cpu().numpy().T
+    rf, rt, _ = ho.step_wrench(fx["state"], np.zeros_like(fx["prev"]), fx["params"], rho, g, dt)
+    assert ho.wrench_error(out0[:, :3], out0[:, 3:], rf, rt, fx["params"], rho, g).max() <= GATE
+    # ... and the engine now holds this step's velocity, exactly (:237-238)
+    assert np.array_equal(eng.get_prev_velocity().cpu().numpy().T, fx["state"][:, 7:13])
+    # checkpoint / resume of the only persistent state
+    eng.set_prev_velocity(fx["prev"])
+    out1 = eng.step_wrench(S, dt).cpu().numpy().T
+    f, t = run_ext(fx["state"], fx["prev"], fx["params"], rho, g, dt)
+    assert np.array_equal(out1[:, :3], f) and np.array_equal(out1[:, 3:], t)
+    eng.reset_prev_velocity()
+    assert float(eng.get_prev_velocity().abs().max()) == 0.0
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2", "c4", "c5"])
+def test_array_of_structs_entry(name, native_built):
+    """The simulator-facing entry (wxyz quaternions, (N,3)/(N,4)/(N,6) tensors, LDS transposition)."""
+    fx = load_golden(name)
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    st = fx["state"]
+    for n in (len(st), 777, 1):
+        eng = HydroEngine(n, DEV, rho, g)
+        eng.set_params(fx["params"][:n], "f16" if name == "c5" else "f32")
+        eng.set_prev_velocity(fx["prev"][:n])
+        pos = torch.from_numpy(np.ascontiguousarray(st[:n, 0:3])).to(DEV)
+        q_wxyz = torch.from_numpy(np.ascontiguousarray(st[:n, [6, 3, 4, 5]])).to(DEV)
+        vel = torch.from_numpy(np.ascontiguousarray(st[:n, 7:13])).to(DEV)
+        F, T = eng.step_wrench_aos(pos, q_wxyz, vel, dt)
+        torch.cuda.synchronize()
+        rf, rt, _ = ho.step_wrench(st[:n], fx["prev"][:n], fx["params"][:n], rho, g, dt)
+        err = ho.wrench_error(F.cpu().numpy(), T.cpu().numpy(), rf, rt, fx["params"][:n], rho, g)
+        assert err.max() <= GATE
+        assert np.array_equal(eng.get_prev_velocity().cpu().numpy().T, st[:n, 7:13])
+        # xyzw order gives the same bits
+        eng.set_prev_velocity(fx["prev"][:n])
+        q_xyzw = torch.from_numpy(np.ascontiguousarray(st[:n, 3:7])).to(DEV)
+        F2, T2 = eng.step_wrench_aos(pos, q_xyzw, vel, dt, quat_xyzw=True)
+        assert torch.equal(F, F2) and torch.equal(T, T2)
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["kat", "c2", "c4"])
+def test_component_mode_matches_reference_outputs(name, native_built):
+    """Eight component vectors + ratio against the reference's own outputs (fixtures)."""
+    fx = load_golden(name)
+    rho, g = float(fx["rho"]), float(fx["g"])
+    n = len(fx["state"])
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(fx["params"])
+    comps, ratio = eng.step_components(soa(fx["state"]), soa(accel_of(fx).astype(np.float32)))
+    torch.cuda.synchronize()
+    eng.close()
+    c = comps.cpu().numpy().T.reshape(n, 8, 3)
+    ref = fx["components"]
+    vol = fx["params"][:, :3].astype(np.float64).prod(1)
+    floor = np.maximum(1e-3 * rho * g * vol, 1e-12)[:, None]
+    rel = np.linalg.norm(c[:, :6] - ref[:, :6], axis=2) / np.maximum(np.linalg.norm(ref[:, :6], axis=2), floor)
+    assert rel.max() < 5e-5                       # per-component (lift near |d|->1 is the worst)
+    assert np.median(rel) < 3e-7
+    # centres are world-space fp32: half an ulp of |p| (~100 m) = 4e-6
+    assert np.abs(c[:, 6:] - ref[:, 6:]).max() < 1e-5 * max(1.0, np.abs(fx["state"][:, :3]).max() / 50)
+    assert np.abs(ratio.cpu().numpy() - fx["ratio"]).max() < 5e-7
+    dry = fx["ratio"] == 0
+    assert np.all(c[dry] == 0.0)                  # Numba semantics: cob = cop = 0 when dry (N6)
+
+
+def test_error_statuses(native_built):
+    fx = load_golden("c2")
+    eng = HydroEngine(128, DEV)
+    S = soa(fx["state"][:256]); P = soa(fx["prev"][:256])
+    with pytest.raises(HydroError, match="HYDRO_E_STATE"):          # step before set_params
+        eng.step_wrench(S[:, :128].contiguous(), 1 / 60)
+    eng.set_params(fx["params"][:128])
+    with pytest.raises(HydroError, match="HYDRO_E_ARG"):            # n > capacity
+        eng.step_wrench(S, 1 / 60, prev=P)
+    with pytest.raises(HydroError, match="HYDRO_E_ARG"):            # dt <= 0
+        eng.step_wrench(S[:, :128].contiguous(), 0.0)
+    with pytest.raises(HydroError, match="HYDRO_E_ARG"):
+        eng.set_tuning(3)
+    assert isinstance(HydroError(-1, "x"), RuntimeError)            # the plugin's except clause catches it
+    with pytest.raises(HydroError, match="HYDRO_E_DEVICE"):
+        HydroEngine(16, "cuda:63")
+    # n == 0 is a no-op, not an error
+    empty = torch.empty((13, 0), device=DEV)
+    assert eng.step_wrench(empty, 1 / 60).shape == (6, 0)
+    eng.close()
+    with pytest.raises(ValueError):
+        HydroEngine(16, "cpu")
+
+
+def test_kinetic_energy_reduction(native_built):
+    sc = scenes.scene_c4(n=100003, seed=5)
+    eng = HydroEngine(sc.n, DEV, sc.rho, sc.g)
+    eng.set_params(sc.params)
+    S = soa(sc.state)
+    a = eng.kinetic_energy(S, rotational=True).cpu().numpy()
+    b = eng.kinetic_energy(S, rotational=True).cpu().numpy()
+    assert np.array_equal(a, b)                                       # deterministic (no atomics)
+    lin = ho.kinetic_energy(sc.state, sc.params, False)[0]
+    tot = ho.kinetic_energy(sc.state, sc.params, True)[0]
+    assert a[0] == pytest.approx(lin, rel=1e-12)                      # fp64 accumulation of exact fp32 products
+    assert a.sum() == pytest.approx(tot, rel=1e-6)
+    only_lin = eng.kinetic_energy(S, rotational=False).cpu().numpy()
+    assert only_lin[1] == 0.0 and only_lin[0] == a[0]
+    eng.close()
+
+
+def _integrate_ref(state, wrench, params, g, dt):
+    s = state.astype(np.float64); w6 = wrench.astype(np.float64); p = params.astype(np.float64)
+    m = p[:, 10]; d = p[:, :3]
+    v = s[:, 7:10] + dt * (w6[:, :3] / m[:, None] + np.array([0, 0, -g]))
+    pos = s[:, :3] + dt * v
+    R = ho._rot_batch(s[:, 3:7])
+    I = (m / 12.0)[:, None] * np.stack([d[:, 1] ** 2 + d[:, 2] ** 2, d[:, 0] ** 2 + d[:, 2] ** 2, d[:, 0] ** 2 + d[:, 1] ** 2], 1)
+    wb = np.einsum("nba,nb->na", R, s[:, 10:13]); tb = np.einsum("nba,nb->na", R, w6[:, 3:])
+    nb = wb + dt * (tb - np.cross(wb, I * wb)) / I
+    w = np.einsum("nab,nb->na", R, nb)
+    q = s[:, 3:7]
+    qv, qw = q[:, :3], q[:, 3]
+    dq = np.concatenate([w * qw[:, None] + np.cross(w, qv), -(w * qv).sum(1, keepdims=True)], 1)
+    qn = q + 0.5 * dt * dq
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    return np.concatenate([pos, qn, v, w], axis=1)
+
+
+def test_integrator_and_closed_loop(native_built):
+    # buoys (C2): the explicit toy integrator is only stable while damping * dt / mass < 2, which
+    # the 0.45 kg SILVER2 links at 120 Hz violate (the reference leaves integration to PhysX)
+    sc = scenes.scene_c2(n=1024)
+    eng = HydroEngine(sc.n, DEV, sc.rho, sc.g)
+    eng.set_params(sc.params)
+    S = soa(sc.state)
+    W = eng.step_wrench(S, sc.dt, prev=soa(sc.prev))
+    S2 = eng.integrate(S, W, sc.dt)
+    torch.cuda.synchronize()
+    ref = _integrate_ref(sc.state, W.cpu().numpy().T, sc.params, sc.g, sc.dt)
+    got = S2.cpu().numpy().T
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(np.linalg.norm(got[:, 3:7], axis=1) - 1).max() < 1e-6
+    # closed loop, ping-pong state buffers: previous velocity = the other buffer's velocity rows
+    A, B = S.clone(), torch.empty_like(S)
+    prev = soa(sc.prev)
+    for k in range(200):
+        W = eng.step_wrench(A, sc.dt, out=W, prev=prev)
+        eng.integrate(A, W, sc.dt, state_out=B)
+        prev = A[7:13]                       # rows 7..12 of a (13,N) tensor are a contiguous (6,N) block
+        A, B = B, A
+    torch.cuda.synchronize()
+    fin = A.cpu().numpy()
+    assert np.isfinite(fin).all()
+    assert np.abs(fin[7:10]).max() < 5.0     # damped, bounded: nothing exploded
+    eng.close()
+
+
+# ---------------- BASELINE full sizes: size-independent properties --------------------------
+@pytest.fixture(scope="module")
+def big_scene():
+    base = scenes.scene_c5(n=131072, seed=55)
+    reps = 8                                   # 1 048 576 bodies (config 5 size)
+    rng = np.random.default_rng(0)
+    idx = np.concatenate([rng.permutation(base.n) for _ in range(reps)])
+    return scenes.Scene("C5", base.state[idx], base.prev[idx], base.params[idx], base.rho, base.g, base.dt, "f16"), base, idx
+
+
+def test_full_size_properties(big_scene, native_built):
+    sc, base, idx = big_scene
+    assert sc.n == 1048576
+    f, t = run_ext(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt, "f16")
+    assert np.isfinite(f).all() and np.isfinite(t).all()
+    # (1) every copy of a body gets the same bits wherever it sits in the launch
+    fb, tb = run_ext(base.state, base.prev, base.params, base.rho, base.g, base.dt, "f16")
+    assert np.array_equal(f, fb[idx]) and np.array_equal(t, tb[idx])
+    # (2) oracle on a strided subsample of the million
+    sub = np.arange(0, sc.n, 257)
+    rf, rt, aux = ho.step_wrench(sc.state[sub], sc.prev[sub], sc.params[sub], sc.rho, sc.g, sc.dt)
+    err = ho.wrench_error(f[sub], t[sub], rf, rt, sc.params[sub], sc.rho, sc.g)
+    assert err.max() <= GATE
+    # (3) dry bodies: exact zeros
+    ext = scenes.vertical_extent(sc.state[:, 3:7], sc.params[:, :3])
+    dry = sc.state[:, 2].astype(np.float64) - ext > 0
+    assert dry.sum() > 200000 and np.all(f[dry] == 0) and np.all(t[dry] == 0)
+    # (4) the wrench does not depend on world x, y
+    st = sc.state.copy(); st[:, 0] += 4321.0; st[:, 1] -= 999.5
+    f2, t2 = run_ext(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt, "f16")
+    assert np.array_equal(f, f2) and np.array_equal(t, t2)
+    # (5) clamp bound holds for every body
+    assert np.all(np.linalg.norm(f.astype(np.float64), axis=1) <= sc.params[:, 10].astype(np.float64) * 500.0 * (1 + 1e-6))
+
+
+def test_sharded_equals_unsharded_bit_for_bit(native_built):
+    """Config 4 (262 144 bodies) cut into 8 contiguous shards of 32 768, as on 8 GPUs."""
+    from silver2_isaacsim_amd.distributed import shard_range
+    sc = scenes.scene_c4(n=262144, seed=4)
+    f, t = run_ext(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    ke_parts = []
+    for r in range(8):
+        lo, hi = shard_range(sc.n, r, 8)
+        assert hi - lo == 32768
+        sh = sc.shard(r, 8)
+        fs, ts = run_ext(sh.state, sh.prev, sh.params, sh.rho, sh.g, sh.dt)
+        assert np.array_equal(fs, f[lo:hi]) and np.array_equal(ts, t[lo:hi])
+        eng = HydroEngine(sh.n, DEV, sh.rho, sh.g); eng.set_params(sh.params)
+        ke_parts.append(eng.kinetic_energy(soa(sh.state)).cpu().numpy()[0]); eng.close()
+    assert sum(ke_parts) == pytest.approx(ho.kinetic_energy(sc.state, sc.params)[0], rel=1e-12)
+
+
+def test_yaw_equivariance_on_device(native_built):
+    sc = scenes.scene_c4(n=65536, seed=12)
+    th = 1.1
+    c, s = np.cos(th), np.sin(th)
+    rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    st = sc.state.astype(np.float64).copy(); pv = sc.prev.astype(np.float64).copy()
+    for a, b in ((0, 3), (7, 10), (10, 13)):
+        st[:, a:b] = st[:, a:b] @ rz.T
+    pv[:, 0:3] = pv[:, 0:3] @ rz.T; pv[:, 3:6] = pv[:, 3:6] @ rz.T
+    x, y, z, w = (sc.state[:, 3 + i].astype(np.float64) for i in range(4))
+    a, b, cc, d = 0.0, 0.0, np.sin(th / 2), np.cos(th / 2)
+    st[:, 3] = d * x + a * w + b * z - cc * y; st[:, 4] = d * y - a * z + b * w + cc * x
+    st[:, 5] = d * z + a * y - b * x + cc * w; st[:, 6] = d * w - a * x - b * y - cc * z
+    f0, t0 = run_ext(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    f1, t1 = run_ext(st.astype(np.float32), pv.astype(np.float32), sc.params, sc.rho, sc.g, sc.dt)
+    # rotated inputs are re-rounded to fp32, so compare with the oracle's metric at a loose gate
+    err = ho.wrench_error(f1, t1, f0.astype(np.float64) @ rz.T, t0.astype(np.float64) @ rz.T, sc.params, sc.rho, sc.g)
+    assert np.percentile(err, 99) < 2e-4

@@ -1,0 +1,172 @@
+"""The reference's plugin surface on the HIP engine, driven through an in-memory simulator host:
+HydrodynamicsBehavior lifecycle (hydrodynamics_behavior.py:48-245) and the calculator
+(warp_hydrodynamics_wrapper.py:79-132 / numba_hydrodynamics_wrapper.py:34-53)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import hydro_oracle as ho
+from silver2_isaacsim_amd import behavior as hb
+from silver2_isaacsim_amd import config as cfg
+from silver2_isaacsim_amd.testing import FakeHost, FakeWorld
+from silver2_isaacsim_amd.wrapper import HipHydrodynamicsWrapper
+
+pytestmark = pytest.mark.gpu
+MAIN_SCENE = ["Obsea_Buoy", "Body"] + [f"{p}_{i}" for p in ("Coxa", "Femur", "Tibia") for i in range(6)]
+
+
+def build_scene(batched, config_path=None, seed=0):
+    """The 20 prims of silver2_isaac_sim.usd that carry the behavior."""
+    rng = np.random.default_rng(seed)
+    world = FakeWorld("cuda:0")
+    host = FakeHost(world, config_path)
+    prims, behaviors = [], []
+    for name in MAIN_SCENE:
+        buoy = name == "Obsea_Buoy"
+        initial = {"xDimension": 1, "yDimension": 1, "zDimension": 3} if buoy else None
+        prim = cfg.AttributeStore(name, f"/World/{'Environment' if buoy else 'SILVER2'}/{name}")
+        pos = (-7, 40, 0.596) if buoy else tuple(np.array([2.0, 10.7, -18.44]) + rng.uniform(-0.3, 0.3, 3))
+        q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
+        vel = np.concatenate([rng.normal(0, 0.2, 3), rng.normal(0, 0.3, 3)])
+        part = cfg.match_part(name, cfg.PART_TABLE)
+        world.add_body(prim.path, pos, q, vel, cfg.PART_MASS.get(part, 700.0))
+        b = hb.HydrodynamicsBehavior(prim, host, batched=batched)
+        b.on_init()
+        if initial:                                   # authored USD values for the buoy (no JSON part matches it)
+            for k, v in initial.items():
+                host.set_exposed_variable(prim, cfg.full_attr_name(k), v)
+        prims.append(prim); behaviors.append(b)
+    return world, host, prims, behaviors
+
+
+def oracle_wrench(world, prims, host, prev6, dt):
+    n = len(prims)
+    g = lambda p, k: host.get_exposed_variable(p, cfg.full_attr_name(k))       # noqa: E731
+    params = np.array([[g(p, "xDimension"), g(p, "yDimension"), g(p, "zDimension"), g(p, "linearDragCoefficient"),
+                        g(p, "angularDragCoefficient"), g(p, "linearDamping"), g(p, "angularDamping"),
+                        g(p, "liftCoefficient"), g(p, "linearAddedMassCoefficient"),
+                        g(p, "angularAddedMassCoefficient"), float(world.masses[i])] for i, p in enumerate(prims)], np.float32)
+    pos = world.positions.cpu().numpy(); q = world.orientations.cpu().numpy(); vel = world.velocities.cpu().numpy()
+    state = np.concatenate([pos, q[:, [1, 2, 3, 0]], vel], axis=1)
+    f, t, _ = ho.step_wrench(state, prev6, params, 1025.0, 9.81, dt)
+    return f, t, params
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_lifecycle_and_wrench_parity(batched, native_built):
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors = build_scene(batched)
+    # on_init created the 12 attributes and applied globals + part overrides
+    tib = prims[MAIN_SCENE.index("Tibia_3")]
+    assert host.get_exposed_variable(tib, cfg.full_attr_name("linearDamping")) == 20.0
+    assert host.get_exposed_variable(prims[0], cfg.full_attr_name("zDimension")) == 3.0
+    for b in behaviors:
+        b.on_play()
+    dt = 1.0 / 60.0
+    n = len(prims)
+    prev = np.zeros((n, 6), np.float32)
+    for step in range(3):
+        host.step(dt)
+        torch.cuda.synchronize()
+        f_ref, t_ref, params = oracle_wrench(world, prims, host, prev, dt)
+        got_f = np.stack([world.applied[p.path][0].cpu().numpy() for p in prims])
+        got_t = np.stack([world.applied[p.path][1].cpu().numpy() for p in prims])
+        err = ho.wrench_error(got_f, got_t, f_ref, t_ref, params, 1025.0, 9.81)
+        assert err.max() <= 1e-5, (step, err.max())
+        prev = world.velocities.cpu().numpy().copy()
+        world.velocities += 0.01 * torch.randn_like(world.velocities)          # "PhysX" moves the bodies
+    # N per-prim callbacks -> one batched launch + one apply call per step (or N in per-prim mode)
+    assert world.apply_calls == (3 if batched else 3 * n)
+    if batched:
+        assert len(host.views) == 1 and len(host.views[0].paths) == n
+    for b in behaviors:
+        b.on_stop()
+    assert not hb.REGISTRY._groups
+    for b in behaviors:
+        b.on_destroy()
+    assert not prims[0].has(cfg.full_attr_name("gravity"))
+
+
+def test_state_fetch_failure_skips_the_step(native_built):
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors = build_scene(True)
+    for b in behaviors:
+        b.on_play()
+    host.step(1 / 60)
+    calls = world.apply_calls
+    host.views[0].fail_next_fetch = True               # RuntimeError inside get_world_poses (:191-192)
+    host.step(1 / 60)
+    assert world.apply_calls == calls                  # skipped, nothing raised
+    host.step(1 / 60)
+    assert world.apply_calls == calls + 1
+    host.step(0.0)                                     # dt <= 1e-6 guard (:139)
+    assert world.apply_calls == calls + 1
+    for b in behaviors:
+        b.on_stop()
+
+
+def test_missing_rigid_body_and_json_override(tmp_path, native_built):
+    hb.REGISTRY.clear()
+    data = cfg.default_config()
+    data["parts"]["coxa"]["linearDamping"] = 11.5
+    import json
+    path = str(tmp_path / cfg.CONFIG_FILE_NAME)
+    json.dump(data, open(path, "w"))
+    world = FakeWorld("cuda:0"); host = FakeHost(world, path)
+    prim = cfg.AttributeStore("Coxa_9"); world.add_body(prim.path, (0, 0, -5), (1, 0, 0, 0), [0] * 6, 0.45)
+    b = hb.HydrodynamicsBehavior(prim, host); b.on_init()
+    assert host.get_exposed_variable(prim, cfg.full_attr_name("linearDamping")) == 11.5
+    ghost = cfg.AttributeStore("Decor", rigid_body=False)
+    g = hb.HydrodynamicsBehavior(ghost, host); g.on_init(); g.on_play()
+    host.step(1 / 60)                                   # no RigidBodyAPI: warned, never registered, no crash
+    assert g._group is None and world.apply_calls == 0
+    b.on_play(); host.step(1 / 60)
+    assert world.apply_calls == 1
+    b.on_stop()
+    # a missing config file keeps the USD values (:79-81)
+    host2 = FakeHost(world, str(tmp_path / "absent.json"))
+    p2 = cfg.AttributeStore("Coxa_1"); b2 = hb.HydrodynamicsBehavior(p2, host2); b2.on_init()
+    assert host2.get_exposed_variable(p2, cfg.full_attr_name("linearDamping")) == 300.0
+
+
+def test_calculator_surface(native_built):
+    """Same ctor keywords / method as the reference calculators; values = the reference's own outputs."""
+    fx = load_golden("kat")
+    names = [str(x) for x in fx["names"]]
+    for i, nm in enumerate(names):
+        p = fx["params"][i]
+        w = HipHydrodynamicsWrapper(width=p[0], depth=p[1], height=p[2], linear_drag_coefficient=p[3],
+                                    angular_drag_coefficient=p[4], linear_damping=p[5], angular_damping=p[6],
+                                    water_density=1025.0, gravity=9.81, linear_mass_coeff=p[8],
+                                    angular_mass_coeff=p[9], lift_coefficient=p[7], device="cuda:0")
+        s, a = fx["state"][i].astype(np.float32), fx["accel"][i].astype(np.float32)
+        out = w.calculate_hydrodynamic_forces(s[0:3], s[3:7], s[7:10], s[10:13], a[0:3], a[3:6])
+        assert len(out) == 8 and all(o.shape == (1, 3) and o.dtype == torch.float32 and o.is_cuda for o in out)
+        ref = fx["components"][i]
+        for k in range(6):
+            got = out[k].cpu().numpy()[0]
+            assert np.abs(got - ref[k]).max() <= 2e-6 * max(1.0, np.abs(ref[k]).max()), (nm, k)
+        assert np.abs(out[6].cpu().numpy()[0] - ref[6]).max() < 1e-5 and np.abs(out[7].cpu().numpy()[0] - ref[7]).max() < 1e-5
+        assert float(w.sub_ratio[0]) == pytest.approx(fx["ratio"][i], abs=2e-7)
+        w.close()
+
+
+def test_calculator_batched_and_fused(native_built):
+    fx = load_golden("c2")
+    n = 512
+    p = fx["params"][:n]
+    w = HipHydrodynamicsWrapper(p[:, 0], p[:, 1], p[:, 2], p[:, 3], p[:, 4], p[:, 5], p[:, 6], 1025.0, 9.81,
+                                p[:, 8], p[:, 9], p[:, 7], device="cuda:0", mass=p[:, 10])
+    st = torch.from_numpy(fx["state"][:n]).cuda()
+    dt = float(fx["dt"])
+    w.engine.set_prev_velocity(fx["prev"][:n])
+    F, T = w.calculate_wrench(st[:, 0:3], st[:, 3:7], st[:, 7:10], st[:, 10:13], dt)
+    rf, rt, _ = ho.step_wrench(fx["state"][:n], fx["prev"][:n], p, 1025.0, 9.81, dt)
+    assert ho.wrench_error(F.cpu().numpy(), T.cpu().numpy(), rf, rt, p, 1025.0, 9.81).max() <= 1e-5
+    buf = F.data_ptr()
+    F2, _ = w.calculate_wrench(st[:, 0:3], st[:, 3:7], st[:, 7:10], st[:, 10:13], dt)
+    assert F2.data_ptr() == buf                        # wrapper-owned, reused buffers (warp wrapper :123-132)
+    with pytest.raises(ValueError):
+        HipHydrodynamicsWrapper(1, 1, 1, 1.2, 0.8, 300, 150, [1025.0, 1000.0], 9.81, 0.05, 0.02, 1.0)
+    w.close()
