@@ -134,8 +134,9 @@ int hydro_integrate(hydro_t *h, int64_t n, const float *const state_in[HYDRO_STA
                     const float *const wrench[HYDRO_WRENCH_FIELDS], float dt,
                     float *const state_out[HYDRO_STATE_FIELDS], void *stream);
 
-/* Kernel-variant selection for tuning (bodies per lane: 1, 2 or 4; 0 = default). */
-int hydro_set_tuning(hydro_t *h, int bodies_per_lane, int block_threads);
+/* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
+ * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1). */
+int hydro_set_tuning(hydro_t *h, int bodies_per_lane, int block_threads, int non_temporal);
 
 int   hydro_sync(hydro_t *h);
 void *hydro_stream(hydro_t *h);

@@ -43,7 +43,7 @@ SIGNATURES = {
     "hydro_step_components": (c_int, [c_void_p, c_int64, _FP, _FP, _FP, c_void_p, c_void_p]),
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
     "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
-    "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int]),
+    "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int]),
     "hydro_sync": (c_int, [c_void_p]),
     "hydro_stream": (c_void_p, [c_void_p]),
 }

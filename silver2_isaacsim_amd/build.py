@@ -36,7 +36,11 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
            "-Wall", "-Wno-unused-function",
            # the SLP vectoriser packs the scalar fp32 math into v_pk_* pairs at the price of ~115
            # v_mov and +24 VGPRs per lane (103 -> 79 without it): occupancy matters more here
-           "-fno-slp-vectorize"] + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
+           "-fno-slp-vectorize",
+           # FMA contraction per source expression only (the HIP default, "fast", contracts across
+           # statements and does so differently in each template instantiation): every kernel
+           # variant, SoA or AoS, 1 or 2 bodies per lane, then returns the same bits for a body
+           "-ffp-contract=on"] + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))

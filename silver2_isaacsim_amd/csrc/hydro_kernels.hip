@@ -29,11 +29,6 @@ constexpr int kKeBlocks = 1024;            // first-stage partials of the KE red
 // --------------------------------------------------------------------------
 // vector load / store helpers: VEC consecutive bodies of one SoA field per lane
 // --------------------------------------------------------------------------
-template <int VEC> struct FVec;
-template <> struct FVec<1> { using type = float; };
-template <> struct FVec<2> { using type = float2; };
-template <> struct FVec<4> { using type = float4; };
-
 // `i` is a 32-bit ELEMENT index; the byte offset is formed in 32 bits on purpose so that the
 // access compiles to the "SGPR base + 32-bit VGPR offset" addressing form (no 64-bit per-lane
 // address arithmetic, no VGPR pairs for addresses).  hydro_create caps capacity at 2^30.
@@ -48,48 +43,65 @@ __device__ __forceinline__ T* at(void* __restrict__ p, uint32_t byte_off)
     return reinterpret_cast<T*>(static_cast<char*>(p) + byte_off);
 }
 
-template <int VEC>
+// NT = non-temporal (streaming) access: every byte of a large scene is touched once per step,
+// so nothing is worth keeping in L2 / Infinity Cache; measured +5..9 % on the SoA kernel.
+template <bool NT, typename V>
+__device__ __forceinline__ V ldg(const V* p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void stg(V* p, V v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int VEC, bool NT>
 __device__ __forceinline__ void load_f32(const float* __restrict__ p, uint32_t i, float (&out)[VEC])
 {
-    using V = typename FVec<VEC>::type;
-    const V v = *at<V>(p, i * 4u);
-    const float* f = reinterpret_cast<const float*>(&v);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) out[j] = f[j];
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_f32(float* __restrict__ p, uint32_t i, const float (&in)[VEC])
-{
-    using V = typename FVec<VEC>::type;
-    V v;
-    float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) f[j] = in[j];
-    *at<V>(p, i * 4u) = v;
-}
-
-template <int VEC>
-__device__ __forceinline__ void load_f16(const __half* __restrict__ p, uint32_t i, float (&out)[VEC])
-{
     if constexpr (VEC == 1) {
-        out[0] = __half2float(*at<__half>(p, i * 2u));
-    } else if constexpr (VEC == 2) {
-        const __half2 h = *at<__half2>(p, i * 2u);
-        out[0] = __low2float(h); out[1] = __high2float(h);
+        out[0] = ldg<NT>(at<float>(p, i * 4u));
     } else {
-        const uint2 raw = *at<uint2>(p, i * 2u);
-        const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
-        const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
-        out[0] = __low2float(a); out[1] = __high2float(a); out[2] = __low2float(b); out[3] = __high2float(b);
+        static_assert(VEC == 2, "SoA kernels are built for 1 or 2 bodies per lane");
+        using V2 = float __attribute__((ext_vector_type(2)));
+        const V2 v = ldg<NT>(at<V2>(p, i * 4u));
+        out[0] = v.x; out[1] = v.y;
     }
 }
 
-template <int VEC, bool HALF>
+template <int VEC, bool NT>
+__device__ __forceinline__ void store_f32(float* __restrict__ p, uint32_t i, const float (&in)[VEC])
+{
+    if constexpr (VEC == 1) {
+        stg<NT>(at<float>(p, i * 4u), in[0]);
+    } else {
+        using V2 = float __attribute__((ext_vector_type(2)));
+        V2 v; v.x = in[0]; v.y = in[1];
+        stg<NT>(at<V2>(p, i * 4u), v);
+    }
+}
+
+__device__ __forceinline__ float half_bits_to_float(unsigned short b) { return __half2float(__ushort_as_half(b)); }
+
+template <int VEC, bool NT>
+__device__ __forceinline__ void load_f16(const __half* __restrict__ p, uint32_t i, float (&out)[VEC])
+{
+    if constexpr (VEC == 1) {
+        out[0] = half_bits_to_float(ldg<NT>(at<unsigned short>(p, i * 2u)));
+    } else {
+        const unsigned int raw = ldg<NT>(at<unsigned int>(p, i * 2u));
+        out[0] = half_bits_to_float((unsigned short)(raw & 0xffffu));
+        out[1] = half_bits_to_float((unsigned short)(raw >> 16));
+    }
+}
+
+template <int VEC, bool HALF, bool NT>
 __device__ __forceinline__ void load_coef(const void* __restrict__ p, uint32_t i, float (&out)[VEC])
 {
-    if constexpr (HALF) load_f16<VEC>(static_cast<const __half*>(p), i, out);
-    else load_f32<VEC>(static_cast<const float*>(p), i, out);
+    if constexpr (HALF) load_f16<VEC, NT>(static_cast<const __half*>(p), i, out);
+    else load_f32<VEC, NT>(static_cast<const float*>(p), i, out);
 }
 
 template <bool HALF>
@@ -142,26 +154,26 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
 // Algorithmic traffic per body: 52 B state + 24 B previous velocity + 44 B (30 B
 // with fp16 coefficients) parameters in, 24 B wrench out (+24 B if WRITE_PREV).
 // --------------------------------------------------------------------------
-template <int VEC, bool HALF, bool WRITE_PREV>
-__global__ void __launch_bounds__(kBlock) wrench_soa_kernel(const SoaArgs a)
+template <int BLOCK, int VEC, bool HALF, bool WRITE_PREV, bool NT>
+__global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
 {
     // Precondition (host side, launch_soa): a.n is a multiple of VEC; the <= VEC-1 leftover
     // bodies go to a second launch of the VEC=1 instance.  32-bit element offsets: the field
     // base pointers stay in SGPRs and every access is "saddr + 32-bit voffset".
     const uint32_t n = (uint32_t)a.n;
-    const uint32_t base = (blockIdx.x * kBlock + threadIdx.x) * VEC;
+    const uint32_t base = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
     if (base >= n) return;
 
     float st[HYDRO_STATE_FIELDS][VEC], pv[HYDRO_PREV_FIELDS][VEC], dm[3][VEC], cf[7][VEC], ms[VEC];
 #pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) load_f32<VEC>(a.st[f], base, st[f]);
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) load_f32<VEC, NT>(a.st[f], base, st[f]);
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) load_f32<VEC>(a.pv[f], base, pv[f]);
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) load_f32<VEC, NT>(a.pv[f], base, pv[f]);
 #pragma unroll
-    for (int f = 0; f < 3; ++f) load_f32<VEC>(a.dims[f], base, dm[f]);
+    for (int f = 0; f < 3; ++f) load_f32<VEC, NT>(a.dims[f], base, dm[f]);
 #pragma unroll
-    for (int f = 0; f < 7; ++f) load_coef<VEC, HALF>(a.coef[f], base, cf[f]);
-    load_f32<VEC>(a.mass, base, ms);
+    for (int f = 0; f < 7; ++f) load_coef<VEC, HALF, NT>(a.coef[f], base, cf[f]);
+    load_f32<VEC, NT>(a.mass, base, ms);
 
     float out[HYDRO_WRENCH_FIELDS][VEC];
 #pragma unroll
@@ -181,10 +193,10 @@ __global__ void __launch_bounds__(kBlock) wrench_soa_kernel(const SoaArgs a)
     }
 
 #pragma unroll
-    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) store_f32<VEC>(a.out[f], base, out[f]);
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) store_f32<VEC, NT>(a.out[f], base, out[f]);
     if constexpr (WRITE_PREV) {
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) store_f32<VEC>(a.pv_out[f], base, st[7 + f]);
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) store_f32<VEC, NT>(a.pv_out[f], base, st[7 + f]);
     }
 }
 
@@ -480,7 +492,9 @@ struct hydro_engine {
     float* prev = nullptr;         // [6][stride]
     double* ke_partials = nullptr; // [2 * kKeBlocks]
     hipStream_t stream = nullptr;
-    int vec = 0;                   // 0 = default
+    int vec = 0;                   // bodies per lane, 0 = default (1)
+    int block = 0;                 // threads per block, 0 = by size
+    int nt = -1;                   // non-temporal accesses: -1 = by size, 0 = off, 1 = on
     char err[512] = {0};
 };
 
@@ -522,12 +536,34 @@ void fill_params(hydro_engine* h, Args& a)
                                    : static_cast<const void*>(h->params + (3 + f) * h->stride);
 }
 
-template <int VEC, bool WRITE_PREV>
-void launch_soa_n(hydro_engine* h, const SoaArgs& a, hipStream_t s)
+// Launch geometry, measured on MI355X (scripts/tune.py, interleaved A/B):
+//   * non-temporal accesses: +5..9 % once the scene is larger than the caches; small scenes keep
+//     temporal accesses so that a few-MB working set stays L2 / Infinity-Cache resident between steps;
+//   * 128-thread blocks: +8..12 % around 1M bodies (finer dispatch granularity shortens the ramp and
+//     the tail of a ~25 us launch), -3 % at 4M where 256 is kept.
+constexpr int64_t kNtMinBodies = 131072;
+constexpr int64_t kBigBlockMinBodies = 2097152;
+
+template <int BLOCK, int VEC, bool WRITE_PREV>
+void launch_soa_b(hydro_engine* h, const SoaArgs& a, hipStream_t s, bool nt)
 {
-    const int grid = grid_for(a.n, kBlock * VEC);
-    if (h->half_coeffs) hipLaunchKernelGGL((wrench_soa_kernel<VEC, true, WRITE_PREV>), dim3(grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((wrench_soa_kernel<VEC, false, WRITE_PREV>), dim3(grid), dim3(kBlock), 0, s, a);
+    const dim3 grid(grid_for(a.n, BLOCK * VEC)), block(BLOCK);
+    if (h->half_coeffs) {
+        if (nt) hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, true, WRITE_PREV, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, true, WRITE_PREV, false>), grid, block, 0, s, a);
+    } else {
+        if (nt) hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, false, WRITE_PREV, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, false, WRITE_PREV, false>), grid, block, 0, s, a);
+    }
+}
+
+template <int VEC, bool WRITE_PREV>
+void launch_soa_n(hydro_engine* h, const SoaArgs& a, hipStream_t s, int64_t n_total)
+{
+    const bool nt = h->nt < 0 ? (n_total >= kNtMinBodies) : (h->nt != 0);
+    const int block = h->block ? h->block : (n_total >= kBigBlockMinBodies ? 256 : 128);
+    if (block == 256) launch_soa_b<256, VEC, WRITE_PREV>(h, a, s, nt);
+    else launch_soa_b<128, VEC, WRITE_PREV>(h, a, s, nt);
 }
 
 // args shifted by `off` bodies (for the ragged remainder of a vector launch)
@@ -553,10 +589,10 @@ void launch_soa(hydro_engine* h, const SoaArgs& a, hipStream_t s)
     if (n_vec > 0) {
         SoaArgs b = a;
         b.n = n_vec;
-        launch_soa_n<VEC, WRITE_PREV>(h, b, s);
+        launch_soa_n<VEC, WRITE_PREV>(h, b, s, a.n);
     }
     if constexpr (VEC > 1) {
-        if (a.n > n_vec) launch_soa_n<1, WRITE_PREV>(h, shifted(a, n_vec, a.n - n_vec, h->half_coeffs), s);
+        if (a.n > n_vec) launch_soa_n<1, WRITE_PREV>(h, shifted(a, n_vec, a.n - n_vec, h->half_coeffs), s, a.n);
     }
 }
 
@@ -594,8 +630,7 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
     a.n = n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec >= 4) launch_soa<4, WRITE_PREV>(h, a, s);
-    else if (vec == 2) launch_soa<2, WRITE_PREV>(h, a, s);
+    if (vec >= 2) launch_soa<2, WRITE_PREV>(h, a, s);
     else launch_soa<1, WRITE_PREV>(h, a, s);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
@@ -869,13 +904,17 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
     return HYDRO_OK;
 }
 
-int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads)
+int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads, int non_temporal)
 {
     if (!h) return HYDRO_E_ARG;
-    if (!(bodies_per_lane == 0 || bodies_per_lane == 1 || bodies_per_lane == 2 || bodies_per_lane == 4))
-        return fail(h, HYDRO_E_ARG, "bodies_per_lane must be 0, 1, 2 or 4");
-    if (!(block_threads == 0 || block_threads == kBlock)) return fail(h, HYDRO_E_ARG, "block_threads must be 0 or 256");
+    if (!(bodies_per_lane == 0 || bodies_per_lane == 1 || bodies_per_lane == 2))
+        return fail(h, HYDRO_E_ARG, "bodies_per_lane must be 0, 1 or 2");
+    if (!(block_threads == 0 || block_threads == 128 || block_threads == 256))
+        return fail(h, HYDRO_E_ARG, "block_threads must be 0, 128 or 256");
+    if (non_temporal < -1 || non_temporal > 1) return fail(h, HYDRO_E_ARG, "non_temporal must be -1, 0 or 1");
     h->vec = bodies_per_lane;
+    h->block = block_threads;
+    h->nt = non_temporal;
     return HYDRO_OK;
 }
 

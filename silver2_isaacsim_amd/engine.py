@@ -95,8 +95,8 @@ class HydroEngine:
         self.n = n
         self.coeff_dtype = coeff_dtype
 
-    def set_tuning(self, bodies_per_lane: int = 0, block_threads: int = 0) -> None:
-        self._check(self._lib.hydro_set_tuning(self._h, bodies_per_lane, block_threads))
+    def set_tuning(self, bodies_per_lane: int = 0, block_threads: int = 0, non_temporal: int = -1) -> None:
+        self._check(self._lib.hydro_set_tuning(self._h, bodies_per_lane, block_threads, non_temporal))
 
     # ------------------------------------------------- previous-velocity state
     def reset_prev_velocity(self) -> None:

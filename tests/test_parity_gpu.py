@@ -25,10 +25,10 @@ def soa(x):
     return torch.from_numpy(scenes.to_soa(x)).to(DEV)
 
 
-def run_ext(state, prev, params, rho, g, dt, coeff="f32", vec=0):
+def run_ext(state, prev, params, rho, g, dt, coeff="f32", vec=0, block=0, nt=-1):
     eng = HydroEngine(len(state), DEV, rho, g)
     eng.set_params(params, coeff)
-    eng.set_tuning(vec)
+    eng.set_tuning(vec, block, nt)
     out = eng.step_wrench(soa(state), dt, prev=soa(prev))
     torch.cuda.synchronize()
     eng.close()
@@ -37,7 +37,7 @@ def run_ext(state, prev, params, rho, g, dt, coeff="f32", vec=0):
 
 
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
-@pytest.mark.parametrize("vec", [1, 2, 4])
+@pytest.mark.parametrize("vec", [1, 2])
 def test_fused_wrench_matches_oracle_on_fixtures(name, vec, native_built):
     fx = load_golden(name)
     rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
@@ -72,7 +72,7 @@ def test_ungated_population_report(native_built):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 257, 1000, 4095])
-@pytest.mark.parametrize("vec", [1, 2, 4])
+@pytest.mark.parametrize("vec", [1, 2])
 def test_ragged_sizes(n, vec, native_built):
     fx = load_golden("c4")
     rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
@@ -80,6 +80,22 @@ def test_ragged_sizes(n, vec, native_built):
     f, t = run_ext(st, pv, pr, rho, g, dt, vec=vec)
     f1, t1 = run_ext(fx["state"], fx["prev"], fx["params"], rho, g, dt, vec=1)
     assert np.array_equal(f, f1[:n]) and np.array_equal(t, t1[:n])          # same bits as the big launch
+
+
+@pytest.mark.parametrize("coeff", ["f32", "f16"])
+def test_every_launch_geometry_gives_the_same_bits(coeff, native_built):
+    """bodies/lane x block size x (non-)temporal accesses: tuning must never change a result."""
+    fx = load_golden("c5")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = 2047                                      # odd: exercises the remainder launch of vec=2
+    ref = None
+    for vec in (1, 2):
+        for block in (128, 256):
+            for nt in (0, 1):
+                f, t = run_ext(fx["state"][:n], fx["prev"][:n], fx["params"][:n], rho, g, dt, coeff, vec, block, nt)
+                if ref is None:
+                    ref = (f, t)
+                assert np.array_equal(f, ref[0]) and np.array_equal(t, ref[1]), (vec, block, nt)
 
 
 def test_output_tail_is_not_touched(native_built):
@@ -90,7 +106,7 @@ def test_output_tail_is_not_touched(native_built):
     eng.set_params(fx["params"][:2048])
     out = torch.full((6, 2048), -777.0, device=DEV)
     S, P = soa(fx["state"][:2048]), soa(fx["prev"][:2048])
-    for vec in (1, 2, 4):
+    for vec in (1, 2):
         out.fill_(-777.0)
         eng.set_tuning(vec)
         lib_n = eng._lib.hydro_step_wrench_ext(eng._h, n, eng._table(S, 13), eng._table(P, 6), float(fx["dt"]),
