@@ -74,21 +74,58 @@ def build_scene(kind: str, n: int, seed: int):
 
 
 class Replica:
-    """One scene replica resident on the GPU: state, previous velocity, engine (params), output."""
+    """One scene replica resident on the GPU: state, previous velocity, engine (params), output.
+    layout 'tiled' = the engine's native tiled-SoA buffers (hydro_step_wrench_tiled),
+    'soa' = plain struct-of-arrays field pointers (hydro_step_wrench_ext)."""
 
-    def __init__(self, sc, coeff: str, dev, roll: int):
+    def __init__(self, sc, coeff: str, dev, roll: int, layout: str = "tiled"):
         idx = np.roll(np.arange(sc.n), roll)
         self.n = sc.n
         self.dt = sc.dt
-        self.state = torch.from_numpy(scenes.to_soa(sc.state[idx])).to(dev)
-        self.prev = torch.from_numpy(scenes.to_soa(sc.prev[idx])).to(dev)
-        self.out = torch.empty((6, sc.n), dtype=torch.float32, device=dev)
+        self.layout = layout
         self.engine = HydroEngine(sc.n, dev, sc.rho, sc.g)
         self.engine.set_params(sc.params[idx], coeff)
+        if layout == "tiled":
+            self.state = torch.from_numpy(scenes.to_tiled(sc.state[idx])).to(dev)
+            self.prev = torch.from_numpy(scenes.to_tiled(sc.prev[idx])).to(dev)
+            self.out = self.engine.alloc_tiled(6, sc.n)
+        else:
+            self.state = torch.from_numpy(scenes.to_soa(sc.state[idx])).to(dev)
+            self.prev = torch.from_numpy(scenes.to_soa(sc.prev[idx])).to(dev)
+            self.out = torch.empty((6, sc.n), dtype=torch.float32, device=dev)
         self.index = idx
 
     def step(self):
-        self.engine.step_wrench(self.state, self.dt, out=self.out, prev=self.prev)
+        if self.layout == "tiled":
+            self.engine.step_wrench_tiled(self.state, self.n, self.dt, out=self.out, prev=self.prev)
+        else:
+            self.engine.step_wrench(self.state, self.dt, out=self.out, prev=self.prev)
+
+    def wrench_rows(self, m: int) -> np.ndarray:
+        """(m,6) host copy of the first m bodies' wrench."""
+        if self.layout == "tiled":
+            tiles = (m + 63) // 64
+            return scenes.from_tiled(self.out[:tiles].cpu().numpy(), m)
+        return self.out[:, :m].cpu().numpy().T
+
+
+def spin_up(replicas, stream, seconds: float):
+    """Untimed: run the same step loop for `seconds` so that the GPU has left its idle power
+    state before anything is measured.  Measured on MI355X: the first ~50 ms after idle run
+    ~9 % slower (25.1 vs 23.0 us per C5 step); W warm-up steps of a ~25 us kernel are far
+    shorter than that.  This happens BEFORE the W warm-up steps and the K timed steps."""
+    if seconds <= 0:
+        return
+    dev = replicas[0].state.device
+    t0 = time.perf_counter()
+    k = 0
+    with torch.cuda.stream(stream):
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(64):
+                replicas[k % len(replicas)].step()
+                k += 1
+            stream.synchronize()
+    torch.cuda.synchronize(dev)
 
 
 def timed_steps(replicas, steps: int, warmup: int, stream, world: int):
@@ -142,7 +179,7 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
         if time.perf_counter() - t0 >= budget_s / 3:
             break
     multi = m * reps_mt / (time.perf_counter() - t0)
-    gpu = replica.out[:, :m].cpu().numpy().T
+    gpu = replica.wrench_rows(m)
     err = hydro_oracle.wrench_error(gpu[:, :3], gpu[:, 3:], ref_f, ref_t, pr, sc.rho, sc.g)
     try:
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -158,15 +195,17 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
     }
 
 
-def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets: int = 4, seed: int = 11):
+def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets: int = 4, seed: int = 11,
+               layout: str = "tiled"):
     """Small untimed-contract measurement for the 'extras' block (not the headline)."""
     sc = build_scene(kind, n, seed)
-    reps = [Replica(sc, coeff, dev, roll=r * 97) for r in range(sets)]
+    reps = [Replica(sc, coeff, dev, roll=r * 97, layout=layout) for r in range(sets)]
+    spin_up(reps, stream, 0.15)
     _, ms = timed_steps(reps, steps, 10, stream, 1)
     for r in reps:
         r.engine.close()
     us = ms * 1e3 / steps
-    return {"n": sc.n, "coeff": coeff, "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
+    return {"n": sc.n, "coeff": coeff, "layout": layout, "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
             "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
 
 
@@ -193,6 +232,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--bodies-per-lane", type=int, default=0)
+    ap.add_argument("--spinup-seconds", type=float, default=1.0,
+                    help="untimed run of the step loop before the W warm-up steps (GPU clock ramp)")
+    ap.add_argument("--layout", default="tiled", choices=["tiled", "soa"],
+                    help="tiled = engine-native tiled SoA (hydro_step_wrench_tiled); soa = plain field pointers")
     args = ap.parse_args()
 
     rank, local_rank, world = hd.env_rank_world()
@@ -207,12 +250,13 @@ def main():
     kind, n_default, coeff, desc = WORKLOADS[args.workload]
     n = args.bodies or n_default
     sc = build_scene(kind, n, seed=5 + rank)
-    replicas = [Replica(sc, coeff, dev, roll=r * 131071) for r in range(args.scenes)]
+    replicas = [Replica(sc, coeff, dev, roll=r * 131071, layout=args.layout) for r in range(args.scenes)]
     if args.bodies_per_lane:
         for r in replicas:
             r.engine.set_tuning(args.bodies_per_lane)
     stream = torch.cuda.Stream(dev)
 
+    spin_up(replicas, stream, args.spinup_seconds)
     wall, ev_ms = timed_steps(replicas, args.steps, args.warmup, stream, world)
     body_steps = sc.n * args.steps * world
     value = body_steps / wall
@@ -230,7 +274,7 @@ def main():
     ke_us = (time.perf_counter() - t0) * 1e6
 
     if rank == 0:
-        traffic = load_traffic(args.workload) if world == 1 and not args.bodies else None
+        traffic = load_traffic(f"{args.workload}:{args.layout}") if world == 1 and not args.bodies else None
         out = {
             "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,13 +283,16 @@ def main():
             "config": {"workload": desc, "bodies_per_gpu": sc.n, "coefficients": coeff,
                        "scene_replicas_per_gpu": args.scenes, "bytes_per_body_step": bpb,
                        "sharding": f"bodies x{world} (no data-path collective)",
-                       "entry_point": "hydro_step_wrench_ext"},
+                       "layout": "tiled SoA [tile][field][64]" if args.layout == "tiled" else "plain SoA",
+                       "entry_point": "hydro_step_wrench_tiled" if args.layout == "tiled" else "hydro_step_wrench_ext"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-                         "kernel": "wrench_soa_kernel", "kernel_us": kernel_us,
+                         "kernel": "wrench_tiled_kernel" if args.layout == "tiled" else "wrench_soa_kernel",
+                         "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": sc.n * bpb,
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS},
+            "spinup_seconds": args.spinup_seconds,
             "global_kinetic_energy_J": [float(x) for x in ke.cpu().tolist()],
             "ke_allreduce_us": ke_us,
         }
@@ -267,6 +314,9 @@ def main():
             ex["c4_262144"] = quick_rate("c4", 262144, "f32", dev, stream, steps=100)
             ex["c5_f32_1048576"] = quick_rate("c4", 1048576, "f32", dev, stream, steps=100)
             ex["f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2)
+            ex["f16_4194304"] = quick_rate("c5", 4194304, "f16", dev, stream, steps=50, sets=2)
+            ex["plain_soa_c5_1048576"] = quick_rate("c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
+            ex["plain_soa_f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
             out["extras"] = ex
         print(json.dumps(out), flush=True)
 

@@ -50,6 +50,7 @@ extern "C" {
 #define HYDRO_PARAM_FIELDS  11
 #define HYDRO_WRENCH_FIELDS  6
 #define HYDRO_COMP_FIELDS   24
+#define HYDRO_TILE          64   /* bodies per tile of the tiled-SoA layout = one wavefront */
 
 typedef struct hydro_engine hydro_t;
 
@@ -102,6 +103,29 @@ int hydro_step_wrench_ext(hydro_t *h, int64_t n, const float *const state[HYDRO_
                           const float *const prev[HYDRO_PREV_FIELDS], float dt,
                           float *const wrench[HYDRO_WRENCH_FIELDS], void *stream);
 
+/* The same fused step on the engine's NATIVE layout, tiled struct-of-arrays: a group of F fields
+ * over n bodies is stored as [ceil(n/64)][F][64] floats, i.e. body i, field f lives at
+ *     base[(i / 64) * tile_stride + f * 64 + (i % 64)]        (tile_stride >= F * 64, in floats).
+ * Coalescing is that of plain SoA; the difference is that the ~28 256-byte runs a wavefront needs
+ * form three contiguous records instead of 28 pieces of 28 arrays (measured +13 % HBM rate at 4M
+ * bodies).  Buffers hold whole tiles (pad the last one) and are 16-byte aligned.
+ *   prev == NULL : previous velocity lives in the engine (read, then overwritten).
+ *   prev != NULL : caller-owned; for a ping-pong integrator pass the previous state buffer
+ *                  + 7 * 64 with its tile stride (the six velocity fields of each state tile). */
+int hydro_step_wrench_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
+                            const float *prev, int64_t prev_tile_stride, float dt,
+                            float *wrench, int64_t wrench_tile_stride, void *stream);
+
+/* Edges of the tiled layout: simulator tensors -> tiled state and tiled
+ * wrench -> forces / torques (both staged through LDS), and a generic plain-SoA <-> tiled
+ * repack of `fields` field pointers. */
+int hydro_pack_state_aos(hydro_t *h, int64_t n, const float *positions, const float *orientations, int quat_xyzw,
+                         const float *velocities, float *state, int64_t state_tile_stride, void *stream);
+int hydro_unpack_wrench_aos(hydro_t *h, int64_t n, const float *wrench, int64_t wrench_tile_stride,
+                            float *forces, float *torques, void *stream);
+int hydro_repack(hydro_t *h, int64_t n, int fields, float *const soa[], float *tiled, int64_t tile_stride,
+                 int to_tiled, void *stream);
+
 /* Same step on the array-of-structs tensors the simulator hands over
  * (RigidPrimView.get_world_poses / get_velocities, hydrodynamics_behavior.py:178-189) and takes
  * back (apply_forces_and_torques_at_pos, :229-234): positions (n,3), orientations (n,4) in the
@@ -127,12 +151,18 @@ int hydro_step_components(hydro_t *h, int64_t n, const float *const state[HYDRO_
  * functionality named by BASELINE.json north_star; absent from the reference. */
 int hydro_kinetic_energy(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], int rotational,
                          double *out_dev, void *stream);
+int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride, int rotational,
+                               double *out_dev, void *stream);
 
 /* Explicit rigid-body step standing in for PhysX in closed-loop runs:
  * semi-implicit Euler with gravity and box inertia.  state_out may alias state_in. */
 int hydro_integrate(hydro_t *h, int64_t n, const float *const state_in[HYDRO_STATE_FIELDS],
                     const float *const wrench[HYDRO_WRENCH_FIELDS], float dt,
                     float *const state_out[HYDRO_STATE_FIELDS], void *stream);
+
+int hydro_integrate_tiled(hydro_t *h, int64_t n, const float *state_in, int64_t in_tile_stride,
+                          const float *wrench, int64_t wrench_tile_stride, float dt,
+                          float *state_out, int64_t out_tile_stride, void *stream);
 
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
  * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1). */

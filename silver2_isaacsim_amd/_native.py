@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhydro.so")
 
 STATE_FIELDS, PREV_FIELDS, PARAM_FIELDS, WRENCH_FIELDS, COMP_FIELDS = 13, 6, 11, 6, 24
+TILE = 64
 
 HYDRO_OK = 0
 STATUS_NAMES = {0: "HYDRO_OK", -1: "HYDRO_E_ARG", -2: "HYDRO_E_ALLOC", -3: "HYDRO_E_LAUNCH",
@@ -38,10 +39,18 @@ SIGNATURES = {
     "hydro_set_prev_velocity": (c_int, [c_void_p, c_int64, _FP, c_int]),
     "hydro_step_wrench": (c_int, [c_void_p, c_int64, _FP, c_float, _FP, c_void_p]),
     "hydro_step_wrench_ext": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
+    "hydro_step_wrench_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
+                                        c_void_p, c_int64, c_void_p]),
+    "hydro_integrate_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
+                                      c_void_p, c_int64, c_void_p]),
+    "hydro_pack_state_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "hydro_unpack_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "hydro_repack": (c_int, [c_void_p, c_int64, c_int, _FP, c_void_p, c_int64, c_int, c_void_p]),
     "hydro_step_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float,
                                       c_void_p, c_void_p, c_void_p]),
     "hydro_step_components": (c_int, [c_void_p, c_int64, _FP, _FP, _FP, c_void_p, c_void_p]),
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
+    "hydro_kinetic_energy_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
     "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int]),
     "hydro_sync": (c_int, [c_void_p]),

@@ -201,6 +201,169 @@ __global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
 }
 
 // --------------------------------------------------------------------------
+// fused wrench, TILED struct-of-arrays (the engine's native layout).
+//
+// A field group with F fields over N bodies is stored as [ceil(N/64)][F][64] floats: inside a
+// tile of 64 bodies (= one wavefront) every field is a contiguous 256-B run, and the tile's
+// fields follow each other.  Body i, field f lives at  base[(i / 64) * tile_stride + f * 64 + i % 64].
+// Coalescing is that of plain SoA (each wave-instruction still reads one 256-B run), but the
+// ~28 runs a wave needs are now 3 contiguous records (3.3 KiB state, 1.5 KiB previous velocity,
+// 2.75 KiB parameters) instead of 28 pieces scattered over 28 arrays: DRAM pages are used whole.
+// Measured (scripts/tune.py, memory-only probes, 4M bodies): 6.1 TB/s against 5.4 TB/s for
+// plain SoA, i.e. the float4-copy ceiling of the box.  All field offsets f*256 B fit the 12-bit
+// immediate of global_load, so a wave needs ONE 32-bit offset register per record.
+// --------------------------------------------------------------------------
+struct TiledArgs {
+    const float* st;  uint32_t st_stride;      // 13 fields
+    const float* pv;  uint32_t pv_stride;      // 6 fields (may alias a previous state buffer + 7*64)
+    float* pv_out;    uint32_t pvo_stride;     // WRITE_PREV only
+    const float* prm;                          // engine-owned: [tiles][11][64] f32, or f16 record (below)
+    float* out;       uint32_t out_stride;     // 6 fields
+    float rho, g, inv_dt;
+    uint32_t n;
+};
+// fp16-coefficient parameter record per tile: [dimx dimy dimz mass][64] f32 (1024 B) then
+// [cd_lin cd_ang damp_lin damp_ang lift am_lin am_ang][64] f16 (896 B) = 1920 B = 480 floats.
+constexpr uint32_t kPrmTileF32 = 11 * 64;
+constexpr uint32_t kPrmTileF16 = 480;
+
+template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT>
+__global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    const uint32_t so = (tile * a.st_stride + lane) * 4u;
+    const uint32_t po = (tile * a.pv_stride + lane) * 4u;
+    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
+#pragma unroll
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so + f * 256u));
+#pragma unroll
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
+    if constexpr (HALF) {
+        const uint32_t qo = tile * (kPrmTileF16 * 4u) + lane * 4u;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
+        const uint32_t ho = tile * (kPrmTileF16 * 4u) + 1024u + lane * 2u;
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
+    } else {
+        const uint32_t qo = tile * (kPrmTileF32 * 4u) + lane * 4u;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
+    }
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
+    const uint32_t oo = (tile * a.out_stride + lane) * 4u;
+    stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo + 256u), w.fy); stg<NT>(at<float>(a.out, oo + 512u), w.fz);
+    stg<NT>(at<float>(a.out, oo + 768u), w.tx); stg<NT>(at<float>(a.out, oo + 1024u), w.ty); stg<NT>(at<float>(a.out, oo + 1280u), w.tz);
+    if constexpr (WRITE_PREV) {
+        const uint32_t wo = (tile * a.pvo_stride + lane) * 4u;
+#pragma unroll
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo + f * 256u), s[7 + f]);
+    }
+}
+
+// SoA parameters [11][stride] -> tiled records (once per hydro_set_params_*)
+__global__ void __launch_bounds__(kBlock) params_to_tiled_kernel(const float* __restrict__ soa, int64_t stride, const __half* __restrict__ coef16,
+                                                                 float* __restrict__ tiled, int half, uint32_t n_pad, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_pad) return;
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    const bool live = i < n;
+    // padding lanes of the last tile get a benign unit box so that nothing in it is NaN
+    float v[11];
+#pragma unroll
+    for (int f = 0; f < 11; ++f) v[f] = live ? soa[f * stride + i] : (f < 3 || f == 10 ? 1.0f : 0.0f);
+    if (half) {
+        float* rec = tiled + (size_t)tile * kPrmTileF16;
+        rec[0 * 64 + lane] = v[0]; rec[1 * 64 + lane] = v[1]; rec[2 * 64 + lane] = v[2]; rec[3 * 64 + lane] = v[10];
+        __half* hrec = reinterpret_cast<__half*>(rec + 256);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) hrec[f * 64 + lane] = live ? coef16[f * stride + i] : __float2half_rn(0.0f);
+    } else {
+        float* rec = tiled + (size_t)tile * kPrmTileF32;
+#pragma unroll
+        for (int f = 0; f < 11; ++f) rec[f * 64 + lane] = v[f];
+    }
+}
+
+// generic field-group repack between plain SoA ([F] pointers) and tiled, either direction
+struct RepackArgs { float* soa[24]; float* tiled; uint32_t tile_stride; int fields; int to_tiled; uint32_t n; };
+__global__ void __launch_bounds__(kBlock) repack_kernel(const RepackArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t t = (i >> 6) * a.tile_stride + (i & 63u);
+    for (int f = 0; f < a.fields; ++f) {
+        if (a.to_tiled) a.tiled[t + f * 64] = a.soa[f][i];
+        else a.soa[f][i] = a.tiled[t + f * 64];
+    }
+}
+
+// simulator tensors (array-of-structs) -> tiled state, through LDS (same staging as the AoS wrench)
+struct PackArgs { const float* pos; const float* quat; const float* vel; int quat_xyzw; float* st; uint32_t st_stride; uint32_t n; };
+__global__ void __launch_bounds__(kBlock) pack_state_aos_kernel(const PackArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kBlock * 9];
+    const int t = threadIdx.x;
+    const uint32_t block0 = blockIdx.x * kBlock;
+    const uint32_t left = a.n - block0;
+    if (left >= (uint32_t)kBlock) {
+        const float4* p4 = reinterpret_cast<const float4*>(a.pos + (size_t)block0 * 3);
+        const float4* v4 = reinterpret_cast<const float4*>(a.vel + (size_t)block0 * 6);
+        if (t < kBlock * 3 / 4) reinterpret_cast<float4*>(lds + kBlock * 6)[t] = p4[t];
+        reinterpret_cast<float4*>(lds)[t] = v4[t];
+        if (t < kBlock * 6 / 4 - kBlock) reinterpret_cast<float4*>(lds)[t + kBlock] = v4[t + kBlock];
+    } else {
+        for (uint32_t k = t; k < left * 3; k += kBlock) lds[kBlock * 6 + k] = a.pos[(size_t)block0 * 3 + k];
+        for (uint32_t k = t; k < left * 6; k += kBlock) lds[k] = a.vel[(size_t)block0 * 6 + k];
+    }
+    __syncthreads();
+    const uint32_t i = block0 + t;
+    if (i >= a.n) return;
+    const float4 q = reinterpret_cast<const float4*>(a.quat)[i];
+    float* rec = a.st + (size_t)(i >> 6) * a.st_stride + (i & 63u);
+    rec[0 * 64] = lds[kBlock * 6 + 3 * t]; rec[1 * 64] = lds[kBlock * 6 + 3 * t + 1]; rec[2 * 64] = lds[kBlock * 6 + 3 * t + 2];
+    if (a.quat_xyzw) { rec[3 * 64] = q.x; rec[4 * 64] = q.y; rec[5 * 64] = q.z; rec[6 * 64] = q.w; }
+    else             { rec[3 * 64] = q.y; rec[4 * 64] = q.z; rec[5 * 64] = q.w; rec[6 * 64] = q.x; }
+#pragma unroll
+    for (int f = 0; f < 6; ++f) rec[(7 + f) * 64] = lds[6 * t + f];
+}
+
+// tiled wrench -> forces (n,3), torques (n,3), through LDS for whole-line stores
+struct UnpackArgs { const float* w; uint32_t w_stride; float* force; float* torque; uint32_t n; };
+__global__ void __launch_bounds__(kBlock) unpack_wrench_aos_kernel(const UnpackArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kBlock * 6];
+    const int t = threadIdx.x;
+    const uint32_t block0 = blockIdx.x * kBlock;
+    const uint32_t i = block0 + t;
+    const uint32_t left = a.n - block0;
+    if (i < a.n) {
+        const float* rec = a.w + (size_t)(i >> 6) * a.w_stride + (i & 63u);
+        lds[3 * t] = rec[0]; lds[3 * t + 1] = rec[64]; lds[3 * t + 2] = rec[128];
+        lds[kBlock * 3 + 3 * t] = rec[192]; lds[kBlock * 3 + 3 * t + 1] = rec[256]; lds[kBlock * 3 + 3 * t + 2] = rec[320];
+    }
+    __syncthreads();
+    if (left >= (uint32_t)kBlock) {
+        if (t < kBlock * 3 / 4) {
+            reinterpret_cast<float4*>(a.force + (size_t)block0 * 3)[t] = reinterpret_cast<const float4*>(lds)[t];
+            reinterpret_cast<float4*>(a.torque + (size_t)block0 * 3)[t] = reinterpret_cast<const float4*>(lds + kBlock * 3)[t];
+        }
+    } else {
+        for (uint32_t k = t; k < left * 3; k += kBlock) {
+            a.force[(size_t)block0 * 3 + k] = lds[k];
+            a.torque[(size_t)block0 * 3 + k] = lds[kBlock * 3 + k];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
 // fused wrench on the simulator's array-of-structs tensors.
 // One block = 256 consecutive bodies.  positions (256x3) and velocities (256x6) are read
 // as whole 16-B chunks (fully coalesced), parked in LDS and picked up per body with
@@ -338,7 +501,8 @@ __global__ void __launch_bounds__(kBlock) components_kernel(const CompArgs a)
 // block -> fixed-order second stage (deterministic, no atomics).
 // --------------------------------------------------------------------------
 struct KeArgs {
-    const float* st[HYDRO_STATE_FIELDS];
+    const float* st[HYDRO_STATE_FIELDS];   // plain SoA field pointers, or tiled base + f*64 (see IntArgs)
+    uint32_t st_stride, shift, mask;
     const float* dims[3];
     const float* mass;
     double* partials;      // [2 * kKeBlocks]
@@ -359,12 +523,13 @@ __global__ void __launch_bounds__(kBlock) ke_partial_kernel(const KeArgs a)
     __shared__ double red[2][kBlock / 64];
     double lin = 0.0, rot = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const uint32_t o = ((uint32_t)i >> a.shift) * a.st_stride + ((uint32_t)i & a.mask);
         const float m = a.mass[i];
-        const float vx = a.st[7][i], vy = a.st[8][i], vz = a.st[9][i];
+        const float vx = a.st[7][o], vy = a.st[8][o], vz = a.st[9][o];
         lin += 0.5 * (double)m * ((double)vx * vx + (double)vy * vy + (double)vz * vz);
         if (a.rotational) {
-            const float qx = a.st[3][i], qy = a.st[4][i], qz = a.st[5][i], qw = a.st[6][i];
-            const float wx = a.st[10][i], wy = a.st[11][i], wz = a.st[12][i];
+            const float qx = a.st[3][o], qy = a.st[4][o], qz = a.st[5][o], qw = a.st[6][o];
+            const float wx = a.st[10][o], wy = a.st[11][o], wz = a.st[12][o];
             const float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
             const float xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
             const float sx = qw * x2, sy = qw * y2, sz = qw * z2;
@@ -409,25 +574,30 @@ __global__ void __launch_bounds__(kBlock) ke_final_kernel(const double* __restri
 // --------------------------------------------------------------------------
 // explicit rigid-body step (stands in for PhysX in closed-loop runs)
 // --------------------------------------------------------------------------
+// One address rule covers both layouts: field k of body i is at  p[k] + (i >> shift) * stride + (i & mask)
+// plain SoA: p[k] = field pointer, shift = 31 (tile index 0), mask = ~0u;  tiled: p[k] = base + k*64, shift 6, mask 63.
 struct IntArgs {
-    const float* si[HYDRO_STATE_FIELDS];
-    const float* w[HYDRO_WRENCH_FIELDS];
-    float* so[HYDRO_STATE_FIELDS];
-    const float* dims[3];
+    const float* si[HYDRO_STATE_FIELDS]; uint32_t si_stride;
+    const float* w[HYDRO_WRENCH_FIELDS]; uint32_t w_stride;
+    float* so[HYDRO_STATE_FIELDS];       uint32_t so_stride;
+    const float* dims[3];                // always the engine's plain-SoA copy
     const float* mass;
+    uint32_t shift, mask;
     float g, dt;
-    int64_t n;
+    uint32_t n;
 };
 
 __global__ void __launch_bounds__(kBlock) integrate_kernel(const IntArgs a)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
+    const uint32_t hi = i >> a.shift, lo = i & a.mask;
+    const uint32_t oi = hi * a.si_stride + lo, ow = hi * a.w_stride + lo, oo = hi * a.so_stride + lo;
     float s[HYDRO_STATE_FIELDS], f[HYDRO_WRENCH_FIELDS];
 #pragma unroll
-    for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) s[k] = a.si[k][i];
+    for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) s[k] = a.si[k][oi];
 #pragma unroll
-    for (int k = 0; k < HYDRO_WRENCH_FIELDS; ++k) f[k] = a.w[k][i];
+    for (int k = 0; k < HYDRO_WRENCH_FIELDS; ++k) f[k] = a.w[k][ow];
     const float m = a.mass[i], inv_m = 1.0f / m, dt = a.dt;
     const float dx = a.dims[0][i], dy = a.dims[1][i], dz = a.dims[2][i];
     // linear: semi-implicit Euler, gravity along -z
@@ -463,10 +633,10 @@ __global__ void __launch_bounds__(kBlock) integrate_kernel(const IntArgs a)
     float nqw = qw - h * (wx * qx + wy * qy + wz * qz);
     const float inv_n = 1.0f / sqrtf(nqx * nqx + nqy * nqy + nqz * nqz + nqw * nqw);
     nqx *= inv_n; nqy *= inv_n; nqz *= inv_n; nqw *= inv_n;
-    a.so[0][i] = px; a.so[1][i] = py; a.so[2][i] = pz;
-    a.so[3][i] = nqx; a.so[4][i] = nqy; a.so[5][i] = nqz; a.so[6][i] = nqw;
-    a.so[7][i] = vx; a.so[8][i] = vy; a.so[9][i] = vz;
-    a.so[10][i] = wx; a.so[11][i] = wy; a.so[12][i] = wz;
+    a.so[0][oo] = px; a.so[1][oo] = py; a.so[2][oo] = pz;
+    a.so[3][oo] = nqx; a.so[4][oo] = nqy; a.so[5][oo] = nqz; a.so[6][oo] = nqw;
+    a.so[7][oo] = vx; a.so[8][oo] = vy; a.so[9][oo] = vz;
+    a.so[10][oo] = wx; a.so[11][oo] = wy; a.so[12][oo] = wz;
 }
 
 __global__ void __launch_bounds__(kBlock) to_half_kernel(const float* __restrict__ src, __half* __restrict__ dst, int64_t n)
@@ -490,11 +660,14 @@ struct hydro_engine {
     float* params = nullptr;       // [11][stride] fp32
     __half* coeffs16 = nullptr;    // [7][stride]
     float* prev = nullptr;         // [6][stride]
+    float* params_tiled = nullptr; // [tiles][11][64] f32 or [tiles][480] (fp16-coefficient record)
+    float* prev_tiled = nullptr;   // [tiles][6][64]
     double* ke_partials = nullptr; // [2 * kKeBlocks]
     hipStream_t stream = nullptr;
     int vec = 0;                   // bodies per lane, 0 = default (1)
     int block = 0;                 // threads per block, 0 = by size
     int nt = -1;                   // non-temporal accesses: -1 = by size, 0 = off, 1 = on
+    bool prev_in_tiled = false;    // which copy of the engine-owned previous velocity is current
     char err[512] = {0};
 };
 
@@ -661,10 +834,38 @@ int set_params(hydro_engine* h, int64_t n, const float* const params[], int on_d
                                h->params + (3 + f) * h->stride, h->coeffs16 + f * h->stride, n);
         HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     }
+    if (n > 0) {
+        const uint32_t n_pad = (uint32_t)((n + 63) / 64 * 64);
+        hipLaunchKernelGGL(params_to_tiled_kernel, dim3(grid_for(n_pad, kBlock)), dim3(kBlock), 0, h->stream,
+                           h->params, h->stride, h->coeffs16, h->params_tiled, half ? 1 : 0, n_pad, (uint32_t)n);
+        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    }
     // the source arrays may be pageable host memory that the caller frees right away
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
     h->half_coeffs = half;
     h->n_params = n;
+    return HYDRO_OK;
+}
+
+int repack(hydro_engine* h, float* const soa[], int fields, float* tiled, int64_t tile_stride, int64_t n, bool to_tiled, hipStream_t s)
+{
+    if (fields > 24) return fail(h, HYDRO_E_ARG, "too many fields");
+    RepackArgs a;
+    for (int f = 0; f < fields; ++f) a.soa[f] = soa[f];
+    a.tiled = tiled; a.tile_stride = (uint32_t)tile_stride; a.fields = fields; a.to_tiled = to_tiled ? 1 : 0; a.n = (uint32_t)n;
+    hipLaunchKernelGGL(repack_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int check_tiled(hydro_engine* h, int64_t n, const void* p, int64_t stride, int fields, const char* what)
+{
+    if (!p) return fail(h, HYDRO_E_ARG, what);
+    if (stride < (int64_t)fields * HYDRO_TILE || stride % 4 != 0) return fail(h, HYDRO_E_ARG, "tile stride too small or not a multiple of 4 floats");
+    if (!aligned_to(p, 16)) return fail(h, HYDRO_E_ARG, "tiled buffers must be 16-byte aligned");
+    // 32-bit byte offsets inside the kernels
+    const int64_t tiles = (n + HYDRO_TILE - 1) / HYDRO_TILE;
+    if (tiles * stride * 4 >= ((int64_t)1 << 32)) return fail(h, HYDRO_E_ARG, "tiled buffer exceeds 4 GiB: split the scene");
     return HYDRO_OK;
 }
 
@@ -713,6 +914,9 @@ int hydro_create(int device, int64_t capacity, hydro_t** out)
     ok = ok && hipMalloc(&h->params, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
     ok = ok && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) == hipSuccess;
     ok = ok && hipMalloc(&h->prev, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
+    ok = ok && hipMalloc(&h->params_tiled, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
+    ok = ok && hipMalloc(&h->prev_tiled, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
+    ok = ok && hipMemsetAsync(h->prev_tiled, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
     ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * 2 * kKeBlocks) == hipSuccess;
     ok = ok && hipMemsetAsync(h->prev, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
@@ -729,6 +933,8 @@ int hydro_destroy(hydro_t* h)
     if (h->params) (void)hipFree(h->params);
     if (h->coeffs16) (void)hipFree(h->coeffs16);
     if (h->prev) (void)hipFree(h->prev);
+    if (h->params_tiled) (void)hipFree(h->params_tiled);
+    if (h->prev_tiled) (void)hipFree(h->prev_tiled);
     if (h->ke_partials) (void)hipFree(h->ke_partials);
     delete h;
     return HYDRO_OK;
@@ -762,6 +968,7 @@ int hydro_reset_prev_velocity(hydro_t* h)
     if (!h) return HYDRO_E_ARG;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
+    HYDRO_HIP(h, hipMemsetAsync(h->prev_tiled, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
@@ -771,6 +978,12 @@ int hydro_get_prev_velocity(hydro_t* h, int64_t n, float* const prev[HYDRO_PREV_
     if (!h) return HYDRO_E_ARG;
     if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    if (h->prev_in_tiled && n > 0) {          // last written by the tiled entry: bring the SoA copy up to date
+        float* rows[HYDRO_PREV_FIELDS];
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
+        int rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, false, h->stream);
+        if (rc) return rc;
+    }
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) {
         if (!prev[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
         HYDRO_HIP(h, hipMemcpyAsync(prev[f], h->prev + f * h->stride, sizeof(float) * n,
@@ -787,6 +1000,12 @@ int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     int rc = copy_fields(h, h->prev, h->stride, prev, HYDRO_PREV_FIELDS, n, on_device);
     if (rc) return rc;
+    if (n > 0) {
+        float* rows[HYDRO_PREV_FIELDS];
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
+        if ((rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, true, h->stream))) return rc;
+    }
+    h->prev_in_tiled = false;
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
@@ -806,6 +1025,118 @@ int hydro_step_wrench_ext(hydro_t* h, int64_t n, const float* const state[HYDRO_
 {
     if (!h) return HYDRO_E_ARG;
     return step_soa<false>(h, n, state, prev, nullptr, dt, wrench, stream);
+}
+
+int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                            const float* prev, int64_t prev_tile_stride, float dt,
+                            float* wrench, int64_t wrench_tile_stride, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if ((rc = check_tiled(h, n, state, state_tile_stride, HYDRO_STATE_FIELDS, "null state"))) return rc;
+    if ((rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench"))) return rc;
+    const bool own_prev = (prev == nullptr);
+    if (!own_prev && (rc = check_tiled(h, n, prev, prev_tile_stride, HYDRO_PREV_FIELDS, "null prev"))) return rc;
+    if (n == 0) return HYDRO_OK;
+    TiledArgs a;
+    a.st = state; a.st_stride = (uint32_t)state_tile_stride;
+    if (own_prev) { a.pv = h->prev_tiled; a.pv_stride = HYDRO_PREV_FIELDS * HYDRO_TILE; a.pv_out = h->prev_tiled; a.pvo_stride = a.pv_stride; h->prev_in_tiled = true; }
+    else { a.pv = prev; a.pv_stride = (uint32_t)prev_tile_stride; a.pv_out = nullptr; a.pvo_stride = 0; }
+    a.prm = h->params_tiled;
+    a.out = wrench; a.out_stride = (uint32_t)wrench_tile_stride;
+    a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
+    const int block = h->block ? h->block : 256;
+    const dim3 grid(grid_for(n, block)), blk(block);
+#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, 0, s, a)
+#define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
+#define HYDRO_TILED_WP(BLOCK, HALF) do { if (own_prev) HYDRO_TILED_NT(BLOCK, HALF, true); else HYDRO_TILED_NT(BLOCK, HALF, false); } while (0)
+#define HYDRO_TILED_HALF(BLOCK) do { if (h->half_coeffs) HYDRO_TILED_WP(BLOCK, true); else HYDRO_TILED_WP(BLOCK, false); } while (0)
+    if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
+#undef HYDRO_TILED_HALF
+#undef HYDRO_TILED_WP
+#undef HYDRO_TILED_NT
+#undef HYDRO_TILED_LAUNCH
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t in_tile_stride,
+                          const float* wrench, int64_t wrench_tile_stride, float dt,
+                          float* state_out, int64_t out_tile_stride, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if ((rc = check_tiled(h, n, state_in, in_tile_stride, HYDRO_STATE_FIELDS, "null state_in"))) return rc;
+    if ((rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench"))) return rc;
+    if ((rc = check_tiled(h, n, state_out, out_tile_stride, HYDRO_STATE_FIELDS, "null state_out"))) return rc;
+    if (n == 0) return HYDRO_OK;
+    IntArgs a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { a.si[f] = state_in + f * HYDRO_TILE; a.so[f] = state_out + f * HYDRO_TILE; }
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) a.w[f] = wrench + f * HYDRO_TILE;
+    a.si_stride = (uint32_t)in_tile_stride; a.w_stride = (uint32_t)wrench_tile_stride; a.so_stride = (uint32_t)out_tile_stride;
+    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
+    a.mass = h->params + 10 * h->stride;
+    a.shift = 6; a.mask = 63u; a.g = h->g; a.dt = dt; a.n = (uint32_t)n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_pack_state_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,
+                         const float* velocities, float* state, int64_t state_tile_stride, void* stream)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "n out of range (0 <= n <= capacity)");
+    if (!positions || !orientations || !velocities) return fail(h, HYDRO_E_ARG, "null tensor pointer");
+    if (!aligned_to(positions, 16) || !aligned_to(orientations, 16) || !aligned_to(velocities, 16))
+        return fail(h, HYDRO_E_ARG, "array-of-structs tensors must be 16-byte aligned");
+    int rc = check_tiled(h, n, state, state_tile_stride, HYDRO_STATE_FIELDS, "null state");
+    if (rc) return rc;
+    if (n == 0) return HYDRO_OK;
+    PackArgs a;
+    a.pos = positions; a.quat = orientations; a.vel = velocities; a.quat_xyzw = quat_xyzw ? 1 : 0;
+    a.st = state; a.st_stride = (uint32_t)state_tile_stride; a.n = (uint32_t)n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipLaunchKernelGGL(pack_state_aos_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_unpack_wrench_aos(hydro_t* h, int64_t n, const float* wrench, int64_t wrench_tile_stride,
+                            float* forces, float* torques, void* stream)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "n out of range (0 <= n <= capacity)");
+    if (!forces || !torques) return fail(h, HYDRO_E_ARG, "null tensor pointer");
+    if (!aligned_to(forces, 16) || !aligned_to(torques, 16)) return fail(h, HYDRO_E_ARG, "array-of-structs tensors must be 16-byte aligned");
+    int rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench");
+    if (rc) return rc;
+    if (n == 0) return HYDRO_OK;
+    UnpackArgs a;
+    a.w = wrench; a.w_stride = (uint32_t)wrench_tile_stride; a.force = forces; a.torque = torques; a.n = (uint32_t)n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipLaunchKernelGGL(unpack_wrench_aos_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_repack(hydro_t* h, int64_t n, int fields, float* const soa[], float* tiled, int64_t tile_stride,
+                 int to_tiled, void* stream)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (n < 0 || n > h->capacity || !soa || fields < 1 || fields > 24) return fail(h, HYDRO_E_ARG, "bad arguments");
+    for (int f = 0; f < fields; ++f) if (!soa[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
+    int rc = check_tiled(h, n, tiled, tile_stride, fields, "null tiled buffer");
+    if (rc) return rc;
+    if (n == 0) return HYDRO_OK;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    return repack(h, soa, fields, tiled, tile_stride, n, to_tiled != 0, static_cast<hipStream_t>(stream));
 }
 
 int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,
@@ -858,14 +1189,8 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
     return HYDRO_OK;
 }
 
-int hydro_kinetic_energy(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], int rotational,
-                         double* out_dev, void* stream)
+static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, double* out_dev, void* stream)
 {
-    int rc = check_common(h, n);
-    if (rc) return rc;
-    if (!state || !out_dev) return fail(h, HYDRO_E_ARG, "null pointer");
-    KeArgs a;
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field"); a.st[f] = state[f]; }
     for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
     a.mass = h->params + 10 * h->stride;
     a.partials = h->ke_partials; a.out = out_dev; a.rotational = rotational; a.n = n;
@@ -877,6 +1202,31 @@ int hydro_kinetic_energy(hydro_t* h, int64_t n, const float* const state[HYDRO_S
     hipLaunchKernelGGL(ke_final_kernel, dim3(1), dim3(kBlock), 0, s, h->ke_partials, blocks, out_dev);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
+}
+
+int hydro_kinetic_energy(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], int rotational,
+                         double* out_dev, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!state || !out_dev) return fail(h, HYDRO_E_ARG, "null pointer");
+    KeArgs a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field"); a.st[f] = state[f]; }
+    a.st_stride = 0; a.shift = 31; a.mask = 0xffffffffu;
+    return ke_launch(h, a, n, rotational, out_dev, stream);
+}
+
+int hydro_kinetic_energy_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride, int rotational,
+                               double* out_dev, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!out_dev) return fail(h, HYDRO_E_ARG, "null pointer");
+    if ((rc = check_tiled(h, n, state, state_tile_stride, HYDRO_STATE_FIELDS, "null state"))) return rc;
+    KeArgs a;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) a.st[f] = state + f * HYDRO_TILE;
+    a.st_stride = (uint32_t)state_tile_stride; a.shift = 6; a.mask = 63u;
+    return ke_launch(h, a, n, rotational, out_dev, stream);
 }
 
 int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STATE_FIELDS],
@@ -896,7 +1246,8 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
     for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) { if (!wrench[f]) return fail(h, HYDRO_E_ARG, "null wrench field"); a.w[f] = wrench[f]; }
     for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
     a.mass = h->params + 10 * h->stride;
-    a.g = h->g; a.dt = dt; a.n = n;
+    a.si_stride = a.w_stride = a.so_stride = 0; a.shift = 31; a.mask = 0xffffffffu;
+    a.g = h->g; a.dt = dt; a.n = (uint32_t)n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);

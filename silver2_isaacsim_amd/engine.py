@@ -130,6 +130,94 @@ class HydroEngine:
         self._check(rc)
         return out
 
+    # ------------------------------------------------- tiled SoA (native layout)
+    @staticmethod
+    def tiles(n: int) -> int:
+        return (int(n) + nat.TILE - 1) // nat.TILE
+
+    def alloc_tiled(self, fields: int, n: int) -> torch.Tensor:
+        """Zeroed (tiles, fields, 64) float32 buffer: body i, field f at [i // 64, f, i % 64]."""
+        return torch.zeros((self.tiles(n), fields, nat.TILE), dtype=torch.float32, device=self.device)
+
+    def _check_tiled(self, t: torch.Tensor, fields: int, n: int) -> None:
+        if (t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous() or t.ndim != 3
+                or t.shape[1] != fields or t.shape[2] != nat.TILE or t.shape[0] < self.tiles(n)):
+            raise ValueError(f"expected contiguous float32 (>= {self.tiles(n)}, {fields}, {nat.TILE}) tensor on {self.device}")
+
+    def to_tiled(self, soa: torch.Tensor, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """(F,N) plain SoA -> (tiles,F,64) tiled, on device (hydro_repack)."""
+        f, n = soa.shape
+        if out is None:
+            out = self.alloc_tiled(f, n)
+        self._check_tiled(out, f, n)
+        self._check(self._lib.hydro_repack(self._h, n, f, self._table(soa, f), out.data_ptr(), f * nat.TILE, 1, self._stream(stream)))
+        return out
+
+    def from_tiled(self, tiled: torch.Tensor, n: int, out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        f = tiled.shape[1]
+        self._check_tiled(tiled, f, n)
+        if out is None:
+            out = torch.empty((f, n), dtype=torch.float32, device=self.device)
+        self._check(self._lib.hydro_repack(self._h, n, f, self._table(out, f), tiled.data_ptr(), f * nat.TILE, 0, self._stream(stream)))
+        return out
+
+    def step_wrench_tiled(self, state: torch.Tensor, n: int, dt: float, out: torch.Tensor | None = None,
+                          prev: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """Fused wrench on tiled buffers: state (tiles,13,64) -> out (tiles,6,64).
+        prev: None = engine-owned previous velocity (read + updated); a (tiles,6,64) tensor; or a
+        (tiles,13,64) STATE tensor whose velocity fields are used in place (ping-pong integrator:
+        pass the previous step's state buffer - nothing is copied)."""
+        self._check_tiled(state, nat.STATE_FIELDS, n)
+        if out is None:
+            out = self.alloc_tiled(nat.WRENCH_FIELDS, n)
+        self._check_tiled(out, nat.WRENCH_FIELDS, n)
+        if prev is None:
+            p_ptr, p_stride = None, 0
+        elif prev.shape[1] == nat.STATE_FIELDS:
+            self._check_tiled(prev, nat.STATE_FIELDS, n)
+            p_ptr, p_stride = prev.data_ptr() + 7 * nat.TILE * 4, nat.STATE_FIELDS * nat.TILE
+        else:
+            self._check_tiled(prev, nat.PREV_FIELDS, n)
+            p_ptr, p_stride = prev.data_ptr(), nat.PREV_FIELDS * nat.TILE
+        self._check(self._lib.hydro_step_wrench_tiled(
+            self._h, n, state.data_ptr(), nat.STATE_FIELDS * nat.TILE, p_ptr, p_stride, float(dt),
+            out.data_ptr(), nat.WRENCH_FIELDS * nat.TILE, self._stream(stream)))
+        return out
+
+    def integrate_tiled(self, state_in: torch.Tensor, wrench: torch.Tensor, n: int, dt: float,
+                        state_out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        if state_out is None:
+            state_out = torch.zeros_like(state_in)
+        for t, f in ((state_in, nat.STATE_FIELDS), (wrench, nat.WRENCH_FIELDS), (state_out, nat.STATE_FIELDS)):
+            self._check_tiled(t, f, n)
+        self._check(self._lib.hydro_integrate_tiled(
+            self._h, n, state_in.data_ptr(), nat.STATE_FIELDS * nat.TILE, wrench.data_ptr(), nat.WRENCH_FIELDS * nat.TILE,
+            float(dt), state_out.data_ptr(), nat.STATE_FIELDS * nat.TILE, self._stream(stream)))
+        return state_out
+
+    def pack_state_aos(self, positions: torch.Tensor, orientations: torch.Tensor, velocities: torch.Tensor,
+                       out: torch.Tensor | None = None, quat_xyzw: bool = False, stream=None) -> torch.Tensor:
+        """Simulator tensors (N,3), (N,4), (N,6) -> tiled state (tiles,13,64)."""
+        n = positions.shape[0]
+        if out is None:
+            out = self.alloc_tiled(nat.STATE_FIELDS, n)
+        self._check_tiled(out, nat.STATE_FIELDS, n)
+        self._check(self._lib.hydro_pack_state_aos(
+            self._h, n, positions.data_ptr(), orientations.data_ptr(), int(bool(quat_xyzw)), velocities.data_ptr(),
+            out.data_ptr(), nat.STATE_FIELDS * nat.TILE, self._stream(stream)))
+        return out
+
+    def unpack_wrench_aos(self, wrench: torch.Tensor, n: int, forces: torch.Tensor | None = None,
+                          torques: torch.Tensor | None = None, stream=None):
+        self._check_tiled(wrench, nat.WRENCH_FIELDS, n)
+        if forces is None:
+            forces = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        if torques is None:
+            torques = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        self._check(self._lib.hydro_unpack_wrench_aos(self._h, n, wrench.data_ptr(), nat.WRENCH_FIELDS * nat.TILE,
+                                                      forces.data_ptr(), torques.data_ptr(), self._stream(stream)))
+        return forces, torques
+
     def step_wrench_aos(self, positions: torch.Tensor, orientations: torch.Tensor, velocities: torch.Tensor,
                         dt: float, forces: torch.Tensor | None = None, torques: torch.Tensor | None = None,
                         quat_xyzw: bool = False, stream=None):
@@ -167,6 +255,11 @@ class HydroEngine:
         """[sum 1/2 m v^2, sum 1/2 w.I.w] as a float64 device tensor of shape (2,)."""
         if out is None:
             out = torch.empty((2,), dtype=torch.float64, device=self.device)
+        if state.ndim == 3:                       # tiled (tiles,13,64): n = bodies with parameters set
+            self._check_tiled(state, nat.STATE_FIELDS, self.n)
+            self._check(self._lib.hydro_kinetic_energy_tiled(self._h, self.n, state.data_ptr(), nat.STATE_FIELDS * nat.TILE,
+                                                             int(bool(rotational)), out.data_ptr(), self._stream(stream)))
+            return out
         self._check(self._lib.hydro_kinetic_energy(self._h, state.shape[1], self._table(state, nat.STATE_FIELDS),
                                                    int(bool(rotational)), out.data_ptr(), self._stream(stream)))
         return out

@@ -297,3 +297,23 @@ def make_scene(name: str, **kw) -> Scene:
 def to_soa(arr: np.ndarray) -> np.ndarray:
     """(N,F) -> contiguous (F,N) float32: one row per SoA field."""
     return np.ascontiguousarray(np.asarray(arr, dtype=np.float32).T)
+
+
+TILE = 64
+
+
+def to_tiled(arr: np.ndarray) -> np.ndarray:
+    """(N,F) -> (ceil(N/64), F, 64) float32, the engine's tiled-SoA layout (last tile zero-padded):
+    body i, field f at [i // 64, f, i % 64]."""
+    a = np.asarray(arr, dtype=np.float32)
+    n, f = a.shape
+    tiles = (n + TILE - 1) // TILE
+    pad = np.zeros((tiles * TILE, f), dtype=np.float32)
+    pad[:n] = a
+    return np.ascontiguousarray(pad.reshape(tiles, TILE, f).transpose(0, 2, 1))
+
+
+def from_tiled(t: np.ndarray, n: int) -> np.ndarray:
+    """Inverse of `to_tiled`: (tiles,F,64) -> (N,F)."""
+    tiles, f, _ = t.shape
+    return np.ascontiguousarray(t.transpose(0, 2, 1).reshape(tiles * TILE, f)[:n])

@@ -231,6 +231,8 @@ def test_kinetic_energy_reduction(native_built):
     assert a.sum() == pytest.approx(tot, rel=1e-6)
     only_lin = eng.kinetic_energy(S, rotational=False).cpu().numpy()
     assert only_lin[1] == 0.0 and only_lin[0] == a[0]
+    t = eng.kinetic_energy(torch.from_numpy(scenes.to_tiled(sc.state)).to(DEV), rotational=True).cpu().numpy()
+    assert np.array_equal(t, a)                                       # tiled layout: same bits
     eng.close()
 
 
@@ -351,3 +353,119 @@ def test_yaw_equivariance_on_device(native_built):
     # rotated inputs are re-rounded to fp32, so compare with the oracle's metric at a loose gate
     err = ho.wrench_error(f1, t1, f0.astype(np.float64) @ rz.T, t0.astype(np.float64) @ rz.T, sc.params, sc.rho, sc.g)
     assert np.percentile(err, 99) < 2e-4
+
+
+# ---------------- tiled struct-of-arrays: the engine's native layout -----------------------
+def tiled(x):
+    return torch.from_numpy(scenes.to_tiled(x)).to(DEV)
+
+
+@pytest.mark.parametrize("name", ["c2", "c4", "c5"])
+@pytest.mark.parametrize("n", [None, 1, 63, 64, 65, 1000])
+def test_tiled_entry_same_bits_as_plain_soa(name, n, native_built):
+    fx = load_golden(name)
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = n or len(fx["state"])
+    coeff = "f16" if name == "c5" else "f32"
+    st, pv, pr = fx["state"][:n], fx["prev"][:n], fx["params"][:n]
+    f_ref, t_ref = run_ext(st, pv, pr, rho, g, dt, coeff)
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(pr, coeff)
+    S = tiled(st)
+    for block in (128, 256):
+        for nt in (0, 1):
+            eng.set_tuning(0, block, nt)
+            out = eng.step_wrench_tiled(S, n, dt, prev=tiled(pv))
+            torch.cuda.synchronize()
+            o = scenes.from_tiled(out.cpu().numpy(), n)
+            assert np.array_equal(o[:, :3], f_ref) and np.array_equal(o[:, 3:], t_ref), (block, nt)
+    # padding lanes of the last tile are never written
+    eng.set_tuning(0, 0, -1)
+    out = torch.full((eng.tiles(n), 6, 64), -5.0, device=DEV)
+    eng.step_wrench_tiled(S, n, dt, out=out, prev=tiled(pv))
+    flat = out.cpu().numpy().transpose(0, 2, 1).reshape(-1, 6)
+    assert np.all(flat[n:] == -5.0)
+    # oracle gate as well
+    rf, rt, _ = ho.step_wrench(st, pv, pr, rho, g, dt)
+    assert ho.wrench_error(flat[:n, :3], flat[:n, 3:], rf, rt, pr, rho, g).max() <= GATE
+    eng.close()
+
+
+def test_tiled_previous_velocity_modes(native_built):
+    fx = load_golden("c4")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = 3000
+    st, pv, pr = fx["state"][:n], fx["prev"][:n], fx["params"][:n]
+    f_ref, t_ref = run_ext(st, pv, pr, rho, g, dt)
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(pr)
+    S = tiled(st)
+    # (a) previous STATE buffer passed in place: its velocity fields are the previous velocity
+    prev_state = np.zeros((n, 13), np.float32); prev_state[:, 7:13] = pv
+    out = eng.step_wrench_tiled(S, n, dt, prev=tiled(prev_state))
+    o = scenes.from_tiled(out.cpu().numpy(), n)
+    assert np.array_equal(o[:, :3], f_ref) and np.array_equal(o[:, 3:], t_ref)
+    # (b) engine-owned: set -> step -> the engine holds this step's velocity; visible through the SoA getter
+    eng.set_prev_velocity(pv)
+    out = eng.step_wrench_tiled(S, n, dt)
+    o = scenes.from_tiled(out.cpu().numpy(), n)
+    assert np.array_equal(o[:, :3], f_ref) and np.array_equal(o[:, 3:], t_ref)
+    assert np.array_equal(eng.get_prev_velocity().cpu().numpy().T, st[:, 7:13])
+    eng.reset_prev_velocity()
+    out0 = scenes.from_tiled(eng.step_wrench_tiled(S, n, dt).cpu().numpy(), n)
+    f0, t0 = run_ext(st, np.zeros_like(pv), pr, rho, g, dt)
+    assert np.array_equal(out0[:, :3], f0) and np.array_equal(out0[:, 3:], t0)
+    eng.close()
+
+
+def test_tiled_edges_pack_unpack_repack(native_built):
+    fx = load_golden("c4")
+    n = 2500
+    st = fx["state"][:n]
+    eng = HydroEngine(n, DEV)
+    eng.set_params(fx["params"][:n])
+    pos = torch.from_numpy(np.ascontiguousarray(st[:, 0:3])).to(DEV)
+    q_wxyz = torch.from_numpy(np.ascontiguousarray(st[:, [6, 3, 4, 5]])).to(DEV)
+    q_xyzw = torch.from_numpy(np.ascontiguousarray(st[:, 3:7])).to(DEV)
+    vel = torch.from_numpy(np.ascontiguousarray(st[:, 7:13])).to(DEV)
+    T = eng.pack_state_aos(pos, q_wxyz, vel)
+    assert np.array_equal(scenes.from_tiled(T.cpu().numpy(), n), st)
+    T2 = eng.pack_state_aos(pos, q_xyzw, vel, quat_xyzw=True)
+    assert torch.equal(T, T2)
+    # repack both ways is exact
+    S = soa(st)
+    assert torch.equal(eng.to_tiled(S)[:, :, :], T)
+    assert torch.equal(eng.from_tiled(T, n), S)
+    # wrench: tiled -> (n,3) forces / torques
+    W = eng.step_wrench_tiled(T, n, float(fx["dt"]), prev=tiled(fx["prev"][:n]))
+    F, Tq = eng.unpack_wrench_aos(W, n)
+    w = scenes.from_tiled(W.cpu().numpy(), n)
+    assert np.array_equal(F.cpu().numpy(), w[:, :3]) and np.array_equal(Tq.cpu().numpy(), w[:, 3:])
+    eng.close()
+
+
+def test_tiled_closed_loop_equals_plain_soa_loop(native_built):
+    """200 ping-pong steps (wrench + integrator) in both layouts give the same trajectory bits."""
+    sc = scenes.scene_c2(n=1000)
+    eng = HydroEngine(sc.n, DEV, sc.rho, sc.g)
+    eng.set_params(sc.params)
+    n = sc.n
+    A, B = soa(sc.state), torch.empty((13, n), device=DEV)
+    prev = soa(sc.prev)
+    At, Bt = tiled(sc.state), eng.alloc_tiled(13, n)
+    prev_t = tiled(sc.prev)
+    W, Wt = torch.empty((6, n), device=DEV), eng.alloc_tiled(6, n)
+    for k in range(200):
+        eng.step_wrench(A, sc.dt, out=W, prev=prev)
+        eng.integrate(A, W, sc.dt, state_out=B)
+        prev = A[7:13]
+        A, B = B, A
+        eng.step_wrench_tiled(At, n, sc.dt, out=Wt, prev=prev_t)
+        eng.integrate_tiled(At, Wt, n, sc.dt, state_out=Bt)
+        prev_t = At                                   # previous STATE buffer, used in place
+        At, Bt = Bt, At
+    torch.cuda.synchronize()
+    fin = A.cpu().numpy().T
+    assert np.isfinite(fin).all() and np.abs(fin[:, 7:10]).max() < 5.0
+    assert np.array_equal(scenes.from_tiled(At.cpu().numpy(), n), fin)
+    eng.close()
