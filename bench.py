@@ -209,6 +209,39 @@ def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets
             "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
 
 
+def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int = 64, replays: int = 40, seed: int = 11):
+    """Launch-bound small scenes: capture `steps_per_graph` consecutive steps (round-robin over 4
+    scene replicas) into one HIP graph and replay it - one host call per 64 physics steps instead
+    of one per step.  The C-ABI step functions are capture-safe (no allocation, no sync)."""
+    sc = build_scene(kind, n, seed)
+    reps = [Replica(sc, coeff, dev, roll=r * 97) for r in range(4)]
+    spin_up(reps, stream, 0.1)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        for k in range(8):
+            reps[k % 4].step()
+        stream.synchronize()
+        with torch.cuda.graph(g, stream=stream):
+            for k in range(steps_per_graph):
+                reps[k % 4].step()
+        for _ in range(5):
+            g.replay()
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(replays):
+            g.replay()
+        e1.record(stream)
+        stream.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (replays * steps_per_graph)
+    del g
+    for r in reps:
+        r.engine.close()
+    return {"n": sc.n, "coeff": coeff, "layout": "tiled", "mode": f"hipGraph x{steps_per_graph} steps",
+            "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
+            "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected
     separately; FETCH_SIZE doubled per the gfx950 correction).  None when not measured."""
@@ -224,8 +257,8 @@ def load_traffic(workload: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
     ap.add_argument("--bodies", type=int, default=0, help="bodies per GPU (default: the workload's)")
     ap.add_argument("--scenes", type=int, default=4, help="scene replicas stepped round-robin per GPU")
@@ -311,6 +344,12 @@ def main():
             ex["c2_4096"] = quick_rate("c2", 4096, "f32", dev, stream, steps=200)
             ex["c3_19456"] = quick_rate("c3", 19456, "f32", dev, stream, steps=200)
             ex["c4_shard_32768"] = quick_rate("c4", 32768, "f32", dev, stream, steps=200)
+            for key, (kind, nn) in {"c2_4096_graph": ("c2", 4096), "c3_19456_graph": ("c3", 19456),
+                                    "c4_shard_32768_graph": ("c4", 32768)}.items():
+                try:
+                    ex[key] = graph_rate(kind, nn, "f32", dev, stream)
+                except Exception as e:                      # noqa: BLE001 - extras never break the headline
+                    ex[key] = {"error": repr(e)}
             ex["c4_262144"] = quick_rate("c4", 262144, "f32", dev, stream, steps=100)
             ex["c5_f32_1048576"] = quick_rate("c4", 1048576, "f32", dev, stream, steps=100)
             ex["f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2)
