@@ -149,7 +149,7 @@ def timed_steps(replicas, steps: int, warmup: int, stream, world: int):
     hd.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device=dev if world > 1 else "cpu")
+    t = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if world > 1 else "cpu")
     hd.all_reduce_max_(t)
     return float(t.item()), float(ev0.elapsed_time(ev1))
 
@@ -277,11 +277,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     hd.init_process_group()
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    # one rank per GPU; HYDRO_BENCH_SHARE_GPU=1 (with HYDRO_DIST_BACKEND=gloo) lets several ranks share
+    # GPU 0 to rehearse the multi-rank path on a single-GPU box
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("HYDRO_BENCH_SHARE_GPU") == "1"
+    if world > 1 and not share and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: local_rank {local_rank} but only {ndev} GPU(s) visible")
+    dev = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     kind, n_default, coeff, desc = WORKLOADS[args.workload]
     n = args.bodies or n_default
+    if n != n_default:
+        desc = f"{desc} [overridden: {n} bodies/GPU]"
     sc = build_scene(kind, n, seed=5 + rank)
     replicas = [Replica(sc, coeff, dev, roll=r * 131071, layout=args.layout) for r in range(args.scenes)]
     if args.bodies_per_lane:
@@ -301,6 +309,7 @@ def main():
     with torch.cuda.stream(stream):
         ke = replicas[0].engine.kinetic_energy(replicas[0].state, rotational=True)
     stream.synchronize()
+    ke = ke.to(hd.collective_device(dev))
     t0 = time.perf_counter()
     hd.global_kinetic_energy(ke)
     torch.cuda.synchronize(dev)

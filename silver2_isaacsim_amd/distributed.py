@@ -43,7 +43,7 @@ def init_process_group(backend: str | None = None, device_id: int | None = None)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("HYDRO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
     if backend == "nccl":
         dev = local_rank if device_id is None else device_id
@@ -51,6 +51,14 @@ def init_process_group(backend: str | None = None, device_id: int | None = None)
         kw["device_id"] = torch.device("cuda", dev)
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return True
+
+
+def collective_device(default: torch.device | str) -> torch.device:
+    """Where tensors handed to a collective must live: the rank's GPU under nccl/RCCL, the CPU
+    under gloo (CPU tests, or a rehearsal of the multi-rank path on a single-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return torch.device(default)
 
 
 def all_reduce_sum_(t: torch.Tensor, async_op: bool = False):
