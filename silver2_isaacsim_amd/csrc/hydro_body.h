@@ -31,6 +31,7 @@
 #pragma once
 
 #include <math.h>
+#include <stdint.h>
 
 #if defined(__HIPCC__)
 #define HYDRO_FN __host__ __device__ __forceinline__
@@ -65,6 +66,28 @@ HYDRO_FN float fast_rcp(float x) {
 #else
     return 1.0f / x;
 #endif
+}
+
+HYDRO_FN uint32_t float_bits(float x) { uint32_t u; __builtin_memcpy(&u, &x, sizeof u); return u; }
+// mask = (mask << 1) | signbit(z): one v_alignbit_b32 on the device
+HYDRO_FN uint32_t shift_in_sign(uint32_t mask, float z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(mask, float_bits(z), 31);
+#else
+    return (mask << 1) | (float_bits(z) >> 31);
+#endif
+}
+// bits of the 27-bit keypoint mask (point p = 9 i + 3 j + k sits at bit 26 - p) whose lattice index
+// along `axis` (0: i, 1: j, 2: k) equals `value` (0, 1, 2 for -1, 0, +1)
+constexpr uint32_t lattice_mask(int axis, int value) {
+    uint32_t m = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) {
+                const int idx = axis == 0 ? i : (axis == 1 ? j : k);
+                if (idx == value) m |= 1u << (26 - (9 * i + 3 * j + k));
+            }
+    return m;
 }
 
 struct BodyIn {
@@ -139,23 +162,28 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     o.wet = wet;
 
     // ---- A3: centre of buoyancy from integer lattice sums (:69-84,99-103) ----
-    // z_ijk < 0 for lattice index (i,j,k); S_a = sum of index a over wet points.
-    float s_i = 0.0f, s_j = 0.0f, s_k = 0.0f, cnt = 0.0f;
+    // z_ijk < 0 for lattice index (i,j,k); S_a = sum of index a over the wet points.  The test is the
+    // sign bit of z (p_z + 0.0f turns an input of -0.0 into +0.0, after which no sum below can be
+    // -0.0).  The 27 sign bits are funnel-shifted into ONE mask register (one v_alignbit_b32 per
+    // keypoint); the count and the three index sums are then popcounts of that mask against
+    // compile-time masks - no per-keypoint compare / select / float accumulation.
+    const float pzc = b.pz + 0.0f;
+    const float zi[3] = {pzc - ex, pzc, pzc + ex};
+    uint32_t wetmask = 0;
 #pragma unroll
-    for (int i = -1; i <= 1; ++i) {
+    for (int i = 0; i < 3; ++i) {
+        const float zij[3] = {zi[i] - ey, zi[i], zi[i] + ey};
 #pragma unroll
-        for (int j = -1; j <= 1; ++j) {
-            const float zij = b.pz + (float)i * ex + (float)j * ey;
-#pragma unroll
-            for (int k = -1; k <= 1; ++k) {
-                const float m = (zij + (float)k * ez < 0.0f) ? 1.0f : 0.0f;
-                cnt += m;
-                if (i != 0) s_i += (float)i * m;
-                if (j != 0) s_j += (float)j * m;
-                if (k != 0) s_k += (float)k * m;
-            }
+        for (int j = 0; j < 3; ++j) {
+            wetmask = shift_in_sign(wetmask, zij[j] - ez);
+            wetmask = shift_in_sign(wetmask, zij[j]);
+            wetmask = shift_in_sign(wetmask, zij[j] + ez);
         }
     }
+    const float cnt = (float)__builtin_popcount(wetmask);
+    const float s_i = (float)(__builtin_popcount(wetmask & lattice_mask(0, 2)) - __builtin_popcount(wetmask & lattice_mask(0, 0)));
+    const float s_j = (float)(__builtin_popcount(wetmask & lattice_mask(1, 2)) - __builtin_popcount(wetmask & lattice_mask(1, 0)));
+    const float s_k = (float)(__builtin_popcount(wetmask & lattice_mask(2, 2)) - __builtin_popcount(wetmask & lattice_mask(2, 0)));
     const bool partial = !dry_by_extent && !fully_in && cnt > 0.0f;
     const float inv_cnt = partial ? fast_rcp(cnt) : 0.0f;
     const float lbx = hx * s_i * inv_cnt, lby = hy * s_j * inv_cnt, lbz = hz * s_k * inv_cnt;   // body frame
@@ -245,14 +273,13 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     const float m_lin = rv * b.am_lin;
     const float m_ang = rv * b.am_ang;
     const float d2x = b.dimx * b.dimx, d2y = b.dimy * b.dimy, d2z = b.dimz * b.dimz;
-    const float abx = r00 * b.ax + r10 * b.ay + r20 * b.az;         // R^T a
-    const float aby = r01 * b.ax + r11 * b.ay + r21 * b.az;
-    const float abz = r02 * b.ax + r12 * b.ay + r22 * b.az;
+    // linear part: the added mass is isotropic (m_lin on all three axes), so
+    //   R (m_lin R^T a) = m_lin (R R^T) a = m_lin (a + kappa (2a - R a - R^T a)),  kappa ~ 1e-7:
+    // a itself to fp32 accuracy - the two rotations the reference performs cancel.
     const float bbx = r00 * b.bx + r10 * b.by + r20 * b.bz;         // R^T alpha
     const float bby = r01 * b.bx + r11 * b.by + r21 * b.bz;
     const float bbz = r02 * b.bx + r12 * b.by + r22 * b.bz;
     const float kf = -m_lin * ratio;
-    const float flx = kf * abx, fly = kf * aby, flz = kf * abz;
     const float kt = -m_ang * ratio;
     const float tlx = kt * (d2y + d2z) * bbx, tly = kt * (d2x + d2z) * bby, tlz = kt * (d2x + d2y) * bbz;
 
@@ -266,9 +293,9 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     o.lift_fx = HYDRO_LIVE(lift_k * (r02 * vhat2 + d_raw * dx));
     o.lift_fy = HYDRO_LIVE(lift_k * (r12 * vhat2 + d_raw * dy));
     o.lift_fz = HYDRO_LIVE(lift_k * (r22 * vhat2 + d_raw * dz));
-    o.am_fx = HYDRO_LIVE(r00 * flx + r01 * fly + r02 * flz);
-    o.am_fy = HYDRO_LIVE(r10 * flx + r11 * fly + r12 * flz);
-    o.am_fz = HYDRO_LIVE(r20 * flx + r21 * fly + r22 * flz);
+    o.am_fx = HYDRO_LIVE(kf * b.ax);
+    o.am_fy = HYDRO_LIVE(kf * b.ay);
+    o.am_fz = HYDRO_LIVE(kf * b.az);
     o.am_tx = HYDRO_LIVE(r00 * tlx + r01 * tly + r02 * tlz);
     o.am_ty = HYDRO_LIVE(r10 * tlx + r11 * tly + r12 * tlz);
     o.am_tz = HYDRO_LIVE(r20 * tlx + r21 * tly + r22 * tlz);

@@ -233,23 +233,24 @@ __global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n) return;
     const uint32_t tile = i >> 6, lane = i & 63u;
-    const uint32_t so = (tile * a.st_stride + lane) * 4u;
-    const uint32_t po = (tile * a.pv_stride + lane) * 4u;
+    // tile < 2^24 and strides < 2^24 (checked on the host): full-rate 24-bit multiplies
+    const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
+    const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
 #pragma unroll
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so + f * 256u));
 #pragma unroll
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
     if constexpr (HALF) {
-        const uint32_t qo = tile * (kPrmTileF16 * 4u) + lane * 4u;
+        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
 #pragma unroll
         for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
         mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
-        const uint32_t ho = tile * (kPrmTileF16 * 4u) + 1024u + lane * 2u;
+        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
     } else {
-        const uint32_t qo = tile * (kPrmTileF32 * 4u) + lane * 4u;
+        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
 #pragma unroll
         for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
 #pragma unroll
@@ -257,11 +258,11 @@ __global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
         mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
     }
     const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
-    const uint32_t oo = (tile * a.out_stride + lane) * 4u;
+    const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
     stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo + 256u), w.fy); stg<NT>(at<float>(a.out, oo + 512u), w.fz);
     stg<NT>(at<float>(a.out, oo + 768u), w.tx); stg<NT>(at<float>(a.out, oo + 1024u), w.ty); stg<NT>(at<float>(a.out, oo + 1280u), w.tz);
     if constexpr (WRITE_PREV) {
-        const uint32_t wo = (tile * a.pvo_stride + lane) * 4u;
+        const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
 #pragma unroll
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo + f * 256u), s[7 + f]);
     }
@@ -861,7 +862,8 @@ int repack(hydro_engine* h, float* const soa[], int fields, float* tiled, int64_
 int check_tiled(hydro_engine* h, int64_t n, const void* p, int64_t stride, int fields, const char* what)
 {
     if (!p) return fail(h, HYDRO_E_ARG, what);
-    if (stride < (int64_t)fields * HYDRO_TILE || stride % 4 != 0) return fail(h, HYDRO_E_ARG, "tile stride too small or not a multiple of 4 floats");
+    if (stride < (int64_t)fields * HYDRO_TILE || stride % 4 != 0 || stride >= (1 << 24))
+        return fail(h, HYDRO_E_ARG, "tile stride too small, too large (>= 2^24) or not a multiple of 4 floats");
     if (!aligned_to(p, 16)) return fail(h, HYDRO_E_ARG, "tiled buffers must be 16-byte aligned");
     // 32-bit byte offsets inside the kernels
     const int64_t tiles = (n + HYDRO_TILE - 1) / HYDRO_TILE;
