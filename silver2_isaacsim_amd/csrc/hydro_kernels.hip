@@ -379,15 +379,13 @@ struct AosArgs {
     const float* vel;       // (n,6)
     float* force;           // (n,3)
     float* torque;          // (n,3)
-    float* pv[HYDRO_PREV_FIELDS];
-    const float* dims[3];
-    const void* coef[7];
-    const float* mass;
+    float* pv;              // engine-owned previous velocity, tiled [tiles][6][64] (read, then updated)
+    const float* prm;       // engine-owned parameters, tiled record (f32 or fp16-coefficient form)
     float rho, g, inv_dt;
     int64_t n;
 };
 
-template <bool HALF>
+template <bool HALF, bool NT>
 __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[kBlock * 6];     // 6 KiB: velocities, then F|T
@@ -399,12 +397,13 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
     const int64_t left = a.n - block0;                      // bodies in this block (>=1)
     const bool whole = left >= kBlock;
 
+    using f4 = float __attribute__((ext_vector_type(4)));
     if (whole) {
-        const float4* p4 = reinterpret_cast<const float4*>(a.pos + block0 * 3);
-        const float4* v4 = reinterpret_cast<const float4*>(a.vel + block0 * 6);
-        if (t < kBlock * 3 / 4) reinterpret_cast<float4*>(lds_pos)[t] = p4[t];
-        reinterpret_cast<float4*>(lds)[t] = v4[t];
-        if (t < kBlock * 6 / 4 - kBlock) reinterpret_cast<float4*>(lds)[t + kBlock] = v4[t + kBlock];
+        const f4* p4 = reinterpret_cast<const f4*>(a.pos + block0 * 3);
+        const f4* v4 = reinterpret_cast<const f4*>(a.vel + block0 * 6);
+        if (t < kBlock * 3 / 4) reinterpret_cast<f4*>(lds_pos)[t] = ldg<NT>(p4 + t);
+        reinterpret_cast<f4*>(lds)[t] = ldg<NT>(v4 + t);
+        if (t < kBlock * 6 / 4 - kBlock) reinterpret_cast<f4*>(lds)[t + kBlock] = ldg<NT>(v4 + t + kBlock);
     } else {
         for (int64_t k = t; k < left * 3; k += kBlock) lds_pos[k] = a.pos[block0 * 3 + k];
         for (int64_t k = t; k < left * 6; k += kBlock) lds[k] = a.vel[block0 * 6 + k];
@@ -414,26 +413,39 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
     const bool live = i < a.n;
     const int64_t ic = live ? i : a.n - 1;                  // clamp: idle lanes redo the last body
     const int tc = (int)(ic - block0);
-    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7];
+    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
     s[0] = lds_pos[3 * tc]; s[1] = lds_pos[3 * tc + 1]; s[2] = lds_pos[3 * tc + 2];
-    const float4 q = reinterpret_cast<const float4*>(a.quat)[ic];
+    const f4 q = ldg<NT>(reinterpret_cast<const f4*>(a.quat) + ic);
     if (a.quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
     else             { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
 #pragma unroll
     for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * tc + f];
+    const uint32_t tile = (uint32_t)ic >> 6, lane = (uint32_t)ic & 63u;
+    const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + lane) * 4u;
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = a.pv[f][ic];
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
+    if constexpr (HALF) {
+        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) d[f] = a.dims[f][ic];
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
+        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
 #pragma unroll
-    for (int f = 0; f < 7; ++f) c[f] = load_coef1<HALF>(a.coef[f], ic);
-    const float mass = a.mass[ic];
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
+    } else {
+        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
+    }
 
     const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
 
     if (live) {
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv[f][i] = s[7 + f];
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv, po + f * 256u), s[7 + f]);
     }
     __syncthreads();                                        // everyone has read its velocity
     lds[3 * t] = w.fx; lds[3 * t + 1] = w.fy; lds[3 * t + 2] = w.fz;
@@ -441,8 +453,8 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
     __syncthreads();
     if (whole) {
         if (t < kBlock * 3 / 4) {
-            reinterpret_cast<float4*>(a.force + block0 * 3)[t] = reinterpret_cast<const float4*>(lds)[t];
-            reinterpret_cast<float4*>(a.torque + block0 * 3)[t] = reinterpret_cast<const float4*>(lds + kBlock * 3)[t];
+            stg<NT>(reinterpret_cast<f4*>(a.force + block0 * 3) + t, reinterpret_cast<const f4*>(lds)[t]);
+            stg<NT>(reinterpret_cast<f4*>(a.torque + block0 * 3) + t, reinterpret_cast<const f4*>(lds + kBlock * 3)[t]);
         }
     } else {
         for (int64_t k = t; k < left * 3; k += kBlock) {
@@ -668,7 +680,8 @@ struct hydro_engine {
     int vec = 0;                   // bodies per lane, 0 = default (1)
     int block = 0;                 // threads per block, 0 = by size
     int nt = -1;                   // non-temporal accesses: -1 = by size, 0 = off, 1 = on
-    bool prev_in_tiled = false;    // which copy of the engine-owned previous velocity is current
+    // the engine-owned previous velocity exists in both layouts; which copy is current:
+    enum PrevCopy { kPrevBoth, kPrevSoa, kPrevTiled } prev_current = kPrevBoth;
     char err[512] = {0};
 };
 
@@ -871,6 +884,23 @@ int check_tiled(hydro_engine* h, int64_t n, const void* p, int64_t stride, int f
     return HYDRO_OK;
 }
 
+// Bring the copy of the engine-owned previous velocity that `want` names up to date (a repack
+// kernel on the caller's stream when the other layout was written last), then mark it as the one
+// that is about to be written.
+int prev_acquire(hydro_engine* h, hydro_engine::PrevCopy want, int64_t n, hipStream_t s)
+{
+    if (h->prev_current != hydro_engine::kPrevBoth && h->prev_current != want && n > 0) {
+        float* rows[HYDRO_PREV_FIELDS];
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
+        const int64_t m = h->n_params;            // every body that may have been stepped
+        int rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, m > n ? m : n,
+                        want == hydro_engine::kPrevTiled, s);
+        if (rc) return rc;
+    }
+    h->prev_current = want;
+    return HYDRO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -972,6 +1002,7 @@ int hydro_reset_prev_velocity(hydro_t* h)
     HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipMemsetAsync(h->prev_tiled, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    h->prev_current = hydro_engine::kPrevBoth;
     return HYDRO_OK;
 }
 
@@ -980,11 +1011,12 @@ int hydro_get_prev_velocity(hydro_t* h, int64_t n, float* const prev[HYDRO_PREV_
     if (!h) return HYDRO_E_ARG;
     if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
-    if (h->prev_in_tiled && n > 0) {          // last written by the tiled entry: bring the SoA copy up to date
+    if (h->prev_current == hydro_engine::kPrevTiled && n > 0) {   // last written in tiled form: refresh the SoA copy
         float* rows[HYDRO_PREV_FIELDS];
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
         int rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, false, h->stream);
         if (rc) return rc;
+        h->prev_current = hydro_engine::kPrevBoth;
     }
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) {
         if (!prev[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
@@ -1007,7 +1039,7 @@ int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
         if ((rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, true, h->stream))) return rc;
     }
-    h->prev_in_tiled = false;
+    h->prev_current = hydro_engine::kPrevBoth;
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
@@ -1018,6 +1050,10 @@ int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STAT
     if (!h) return HYDRO_E_ARG;
     float* pv[HYDRO_PREV_FIELDS];
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = h->prev + f * h->stride;
+    if (n > 0 && n <= h->capacity && hipSetDevice(h->device) == hipSuccess) {
+        int rc = prev_acquire(h, hydro_engine::kPrevSoa, n, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
     return step_soa<true>(h, n, state, pv, pv, dt, wrench, stream);
 }
 
@@ -1043,13 +1079,14 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
     if (n == 0) return HYDRO_OK;
     TiledArgs a;
     a.st = state; a.st_stride = (uint32_t)state_tile_stride;
-    if (own_prev) { a.pv = h->prev_tiled; a.pv_stride = HYDRO_PREV_FIELDS * HYDRO_TILE; a.pv_out = h->prev_tiled; a.pvo_stride = a.pv_stride; h->prev_in_tiled = true; }
+    if (own_prev) { a.pv = h->prev_tiled; a.pv_stride = HYDRO_PREV_FIELDS * HYDRO_TILE; a.pv_out = h->prev_tiled; a.pvo_stride = a.pv_stride; }
     else { a.pv = prev; a.pv_stride = (uint32_t)prev_tile_stride; a.pv_out = nullptr; a.pvo_stride = 0; }
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = (uint32_t)wrench_tile_stride;
     a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (own_prev && (rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
     const int block = h->block ? h->block : 256;
     const dim3 grid(grid_for(n, block)), blk(block);
@@ -1155,15 +1192,21 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     if (n == 0) return HYDRO_OK;
     AosArgs a;
     a.pos = positions; a.quat = orientations; a.quat_xyzw = quat_xyzw ? 1 : 0; a.vel = velocities; a.force = forces; a.torque = torques;
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) a.pv[f] = h->prev + f * h->stride;
-    fill_params(h, a);
-    a.mass = h->params + 10 * h->stride;
+    if (n > ((int64_t)1 << 26)) return fail(h, HYDRO_E_ARG, "array-of-structs entry handles at most 2^26 bodies per call");
+    a.pv = h->prev_tiled; a.prm = h->params_tiled;
     a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const int grid = grid_for(n, kBlock);
-    if (h->half_coeffs) hipLaunchKernelGGL(wrench_aos_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL(wrench_aos_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
+    const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
+    if (h->half_coeffs) {
+        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((wrench_aos_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    } else {
+        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((wrench_aos_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    }
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }

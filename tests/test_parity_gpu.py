@@ -469,3 +469,35 @@ def test_tiled_closed_loop_equals_plain_soa_loop(native_built):
     assert np.isfinite(fin).all() and np.abs(fin[:, 7:10]).max() < 5.0
     assert np.array_equal(scenes.from_tiled(At.cpu().numpy(), n), fin)
     eng.close()
+
+
+def test_engine_owned_previous_velocity_is_coherent_across_entry_points(native_built):
+    """Plain-SoA, tiled and array-of-structs entries share ONE previous-velocity state."""
+    fx = load_golden("c4")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = 1500
+    st, pr = fx["state"][:n], fx["params"][:n]
+    rng = np.random.default_rng(3)
+    states = [st.copy() for _ in range(4)]
+    for k, s_ in enumerate(states):
+        s_[:, 7:13] += rng.normal(0, 0.05, (n, 6)).astype(np.float32) * k
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(pr)
+    prev = np.zeros((n, 6), np.float32)
+    outs = []
+    for k, s_ in enumerate(states):
+        if k % 3 == 0:
+            o = eng.step_wrench(soa(s_), dt).cpu().numpy().T
+        elif k % 3 == 1:
+            o = scenes.from_tiled(eng.step_wrench_tiled(tiled(s_), n, dt).cpu().numpy(), n)
+        else:
+            pos = torch.from_numpy(np.ascontiguousarray(s_[:, 0:3])).to(DEV)
+            q = torch.from_numpy(np.ascontiguousarray(s_[:, 3:7])).to(DEV)
+            vel = torch.from_numpy(np.ascontiguousarray(s_[:, 7:13])).to(DEV)
+            F, T = eng.step_wrench_aos(pos, q, vel, dt, quat_xyzw=True)
+            o = np.concatenate([F.cpu().numpy(), T.cpu().numpy()], axis=1)
+        f_ref, t_ref = run_ext(s_, prev, pr, rho, g, dt)
+        assert np.array_equal(o[:, :3], f_ref) and np.array_equal(o[:, 3:], t_ref), k
+        prev = s_[:, 7:13].copy()
+        assert np.array_equal(eng.get_prev_velocity().cpu().numpy().T, prev)
+    eng.close()
