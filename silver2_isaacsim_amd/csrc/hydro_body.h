@@ -140,15 +140,15 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     const double zhi = (double)b.pz + extent;           // highest keypoint (z_max)
     const float r20 = (float)d20, r21 = (float)d21, r22 = (float)d22;
     const float ex = (float)dex, ey = (float)dey, ez = (float)dez;
-    // The quaternion is used as given (N7).  With |q|^2 = 1 + e the matrix above is
-    // R = R^ + e (R^ - I) for the true rotation R^, hence exactly
-    //     R R^T = I + kappa (2I - R^ - R^T),   |R[:,2]|^2 = 1 + 2 kappa (1 - R^22),   kappa = e + e^2.
+    // The quaternion is used as given, never normalised (N7).  With e = |q|^2 - 1 the matrix above is
+    // R = (1+e) R^ - e I for the true rotation R^, which gives the EXACT identities
+    //     R R^T = R^T R = (1 + 2e) I - e (R + R^T),        |R[:,2]|^2 - 1 = 2 e (1 - R22).
     // e ~ 1e-7 for an fp32-rounded unit quaternion: invisible to fp32 arithmetic, but the fp64
-    // reference carries it into two terms that otherwise cancel exactly (below), so it is
-    // evaluated here in fp64 and applied analytically.
+    // reference carries it into terms that otherwise cancel exactly (CoP lever arm x drag, 1 - d^2 in
+    // the lift coefficient, R R^T a in the added mass), so e is evaluated here in fp64 and those
+    // terms are written with the identities - exact for ANY quaternion, unit or not.
     const double qerr = ((dqx * dqx + dqy * dqy) + (dqz * dqz + dqw * dqw)) - 1.0;
     const float qe = (float)qerr;
-    const float kappa = (float)(qerr + qerr * qerr);
 
     // ---- A3: submersion ratio (numba_hydrodynamics.py:86-96) ----
     const bool dry_by_extent = zlo >= 0.0;
@@ -221,22 +221,34 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     float armp_z = r20 * lpx + r21 * lpy + r22 * lpz;
     if (!has_area) { armp_x = armb_x; armp_y = armb_y; armp_z = armb_z; }     // cop = cob (:115,140)
     // arm_p x v_hat without cancellation.  h_a * area_a = V/2 on every axis, so
-    //     arm_p = -(V/2A) R W u,   u = R^T v_hat,   W = diag(face of axis a opposes the flow and is wet)
+    //     arm_p = -(V/2A) R a,   a = W u,   u = R^T v_hat,   W = diag(face of axis a opposes the flow and is wet)
     // which is parallel to v_hat (no torque from drag) when all three opposing faces are wet, up
-    // to the non-orthogonality of R.  With a = W u, c = (I - W) u (complementary supports, so
-    // X = a x c has ONE product per component) and Y = a x v_hat, to first order in e = |q|^2 - 1:
-    //     (R a) x v_hat = R X + e [ (X - R X) + (R Y - Y) ]
+    // to the non-orthogonality of R.  With c = (I - W) u = u - a and R R^T = (1+2e) I - e (R + R^T):
+    //     (R a) x v_hat  =  -e (R v_hat + u) x v_hat  -  (R c) x v_hat          (exact)
+    // Use the direct form when |a| <= |c| and the complement form otherwise: the vector that is
+    // rotated and crossed with v_hat is then at least 45 degrees away from it - no cancellation.
     const bool cx = fax != 0.0f, cy = fay != 0.0f, cz = faz != 0.0f;
-    const float wux = cx ? ux : 0.0f, wuy = cy ? uy : 0.0f, wuz = cz ? uz : 0.0f;     // a = W u
-    const float gux = cx ? 0.0f : ux, guy = cy ? 0.0f : uy, guz = cz ? 0.0f : uz;     // c = (I-W) u
-    const float Xx = wuy * guz - wuz * guy, Xy = wuz * gux - wux * guz, Xz = wux * guy - wuy * gux;
-    const float Yx = wuy * dz - wuz * dy, Yy = wuz * dx - wux * dz, Yz = wux * dy - wuy * dx;
-    const float RXx = r00 * Xx + r01 * Xy + r02 * Xz, RXy = r10 * Xx + r11 * Xy + r12 * Xz, RXz = r20 * Xx + r21 * Xy + r22 * Xz;
-    const float RYx = r00 * Yx + r01 * Yy + r02 * Yz, RYy = r10 * Yx + r11 * Yy + r12 * Yz, RYz = r20 * Yx + r21 * Yy + r22 * Yz;
+    const float ux2 = ux * ux, uy2 = uy * uy, uz2 = uz * uz;
+    const float a2 = (cx ? ux2 : 0.0f) + (cy ? uy2 : 0.0f) + (cz ? uz2 : 0.0f);
+    const float c2 = (cx ? 0.0f : ux2) + (cy ? 0.0f : uy2) + (cz ? 0.0f : uz2);
+    const bool direct = a2 <= c2;
+    const float sxv = (cx == direct) ? ux : 0.0f;                   // direct: a, complement: c
+    const float syv = (cy == direct) ? uy : 0.0f;
+    const float szv = (cz == direct) ? uz : 0.0f;
+    const float rsx = r00 * sxv + r01 * syv + r02 * szv;            // R a  or  R c
+    const float rsy = r10 * sxv + r11 * syv + r12 * szv;
+    const float rsz = r20 * sxv + r21 * syv + r22 * szv;
+    const float rvx = r00 * dx + r01 * dy + r02 * dz;               // R v_hat
+    const float rvy = r10 * dx + r11 * dy + r12 * dz;
+    const float rvz = r20 * dx + r21 * dy + r22 * dz;
+    // complement: (R a) = -e (R v_hat + u) - R c + (1+2e) v_hat, and the v_hat part drops out of the cross product
+    const float wx_ = direct ? rsx : -(qe * (rvx + ux) + rsx);
+    const float wy_ = direct ? rsy : -(qe * (rvy + uy) + rsy);
+    const float wz_ = direct ? rsz : -(qe * (rvz + uz) + rsz);
     const float nhva = -0.5f * (b.dimx * b.dimy * b.dimz) * inv_area;              // -(V/2A)
-    float pxv_x = nhva * (RXx + qe * ((Xx - RXx) + (RYx - Yx)));                  // arm_p x v_hat
-    float pxv_y = nhva * (RXy + qe * ((Xy - RXy) + (RYy - Yy)));
-    float pxv_z = nhva * (RXz + qe * ((Xz - RXz) + (RYz - Yz)));
+    float pxv_x = nhva * (wy_ * dz - wz_ * dy);                                    // arm_p x v_hat
+    float pxv_y = nhva * (wz_ * dx - wx_ * dz);
+    float pxv_z = nhva * (wx_ * dy - wy_ * dx);
     if (!has_area) {
         pxv_x = armb_y * dz - armb_z * dy; pxv_y = armb_z * dx - armb_x * dz; pxv_z = armb_x * dy - armb_y * dx;
     }
@@ -256,13 +268,13 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     // dir = (v_hat x up) x v_hat / |v_hat x up| = (up |v_hat|^2 + d_raw v_hat) / |v_hat x up|
     const float d_raw = -(r02 * dx + r12 * dy + r22 * dz);
     // 1 - d^2 is taken from |v_hat x up|^2 = |up|^2 - d^2 (no cancellation as |d| -> 1):
-    //     sqrt(1 - d^2) / |axis| = sqrt(max(0, 1 - eta / |axis|^2)),  eta = |up|^2 - 1 = 2 kappa (1 - R22).
+    //     sqrt(1 - d^2) / |axis| = sqrt(max(0, 1 - eta / |axis|^2)),  eta = |up|^2 - 1 = 2 e (1 - R22)  (exact).
     const float dcl = fminf(1.0f, fmaxf(-1.0f, d_raw));
     const float axx = dy * r22 - dz * r12, axy = dz * r02 - dx * r22, axz = dx * r12 - dy * r02;
     const float n_axis2 = axx * axx + axy * axy + axz * axz;
     const float n_axis = fast_sqrt(n_axis2);
     const bool lift_on = !(speed < kSpeedEps) && !(n_axis < kAxisEps);
-    const float eta = 2.0f * kappa * (1.0f - r22);
+    const float eta = 2.0f * qe * (1.0f - r22);
     const float clamp_on = (fabsf(d_raw) < 1.0f) ? 1.0f : 0.0f;    // |d| >= 1 -> asin(+-1): C_L = sin(+-pi) = 0
     const float c_l_over_n = 2.0f * dcl * clamp_on * fast_sqrt(fmaxf(0.0f, 1.0f - eta * fast_rcp(n_axis2)));
     const float vhat2 = dx * dx + dy * dy + dz * dz;
@@ -273,9 +285,13 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     const float m_lin = rv * b.am_lin;
     const float m_ang = rv * b.am_ang;
     const float d2x = b.dimx * b.dimx, d2y = b.dimy * b.dimy, d2z = b.dimz * b.dimz;
-    // linear part: the added mass is isotropic (m_lin on all three axes), so
-    //   R (m_lin R^T a) = m_lin (R R^T) a = m_lin (a + kappa (2a - R a - R^T a)),  kappa ~ 1e-7:
-    // a itself to fp32 accuracy - the two rotations the reference performs cancel.
+    // linear part: the added mass is isotropic (m_lin on all three axes), so the two rotations the
+    // reference performs collapse:  R (m_lin R^T a) = m_lin (R R^T) a = m_lin ((1+2e) a - e (R + R^T) a).
+    const float s01 = r01 + r10, s02 = r02 + r20, s12 = r12 + r21;                 // R + R^T (symmetric)
+    const float sax = 2.0f * r00 * b.ax + s01 * b.ay + s02 * b.az;
+    const float say = s01 * b.ax + 2.0f * r11 * b.ay + s12 * b.az;
+    const float saz = s02 * b.ax + s12 * b.ay + 2.0f * r22 * b.az;
+    const float one2e = 1.0f + 2.0f * qe;
     const float bbx = r00 * b.bx + r10 * b.by + r20 * b.bz;         // R^T alpha
     const float bby = r01 * b.bx + r11 * b.by + r21 * b.bz;
     const float bbz = r02 * b.bx + r12 * b.by + r22 * b.bz;
@@ -293,9 +309,9 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     o.lift_fx = HYDRO_LIVE(lift_k * (r02 * vhat2 + d_raw * dx));
     o.lift_fy = HYDRO_LIVE(lift_k * (r12 * vhat2 + d_raw * dy));
     o.lift_fz = HYDRO_LIVE(lift_k * (r22 * vhat2 + d_raw * dz));
-    o.am_fx = HYDRO_LIVE(kf * b.ax);
-    o.am_fy = HYDRO_LIVE(kf * b.ay);
-    o.am_fz = HYDRO_LIVE(kf * b.az);
+    o.am_fx = HYDRO_LIVE(kf * (one2e * b.ax - qe * sax));
+    o.am_fy = HYDRO_LIVE(kf * (one2e * b.ay - qe * say));
+    o.am_fz = HYDRO_LIVE(kf * (one2e * b.az - qe * saz));
     o.am_tx = HYDRO_LIVE(r00 * tlx + r01 * tly + r02 * tlz);
     o.am_ty = HYDRO_LIVE(r10 * tlx + r11 * tly + r12 * tlz);
     o.am_tz = HYDRO_LIVE(r20 * tlx + r21 * tly + r22 * tlz);

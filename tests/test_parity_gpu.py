@@ -501,3 +501,19 @@ def test_engine_owned_previous_velocity_is_coherent_across_entry_points(native_b
         prev = s_[:, 7:13].copy()
         assert np.array_equal(eng.get_prev_velocity().cpu().numpy().T, prev)
     eng.close()
+
+
+@pytest.mark.parametrize("scale", [1.0 + 1e-5, 1.001, 1.02, 0.9])
+def test_non_unit_quaternions_are_used_as_given(scale, native_built):
+    """N7: the reference never normalises the quaternion.  The kernels' cancellation-free forms rest on
+    exact identities in e = |q|^2 - 1, so parity must hold for any |q|, not just for fp32-rounded unit ones."""
+    sc = scenes.scene_c4(n=32768, seed=21)
+    st = sc.state.copy()
+    st[:, 3:7] = (st[:, 3:7].astype(np.float64) * scale).astype(np.float32)
+    ext = scenes.vertical_extent(st[:, 3:7], sc.params[:, :3]); ext0 = scenes.vertical_extent(sc.state[:, 3:7], sc.params[:, :3])
+    st[:, 2] = (sc.state[:, 2].astype(np.float64) * ext / ext0).astype(np.float32)     # keep dry/partial/full classes
+    keep = scenes.branch_margins(st, sc.params) > 1e-4
+    f, t = run_ext(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    rf, rt, _ = ho.step_wrench(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
+    err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)[keep]
+    assert np.percentile(err, 99.9) < 3e-6 and (err > GATE).sum() <= 1
