@@ -100,3 +100,9 @@ def test_non_unit_quaternions_host(scale, emul):
     rf, rt, _ = ho.step_wrench(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)[keep]
     assert np.percentile(err, 99.9) < 3e-6 and (err > 2.5e-5).sum() == 0
+
+
+def test_degenerate_inputs_host(emul):
+    import edge_cases as ec
+    f, t, r = emul(ec.STATE, ec.PREV, ec.PARAMS, ec.RHO, ec.G, ec.DT)
+    ec.check(f, t, r)

@@ -517,3 +517,16 @@ def test_non_unit_quaternions_are_used_as_given(scale, native_built):
     rf, rt, _ = ho.step_wrench(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)[keep]
     assert np.percentile(err, 99.9) < 3e-6 and (err > GATE).sum() <= 1
+
+
+def test_degenerate_inputs(native_built):
+    """Zero dimensions / mass / speed, faces exactly on the surface, -0.0, clamp, 10 km offsets."""
+    import edge_cases as ec
+    f, t = run_ext(ec.STATE, ec.PREV, ec.PARAMS, ec.RHO, ec.G, ec.DT)
+    ec.check(f, t)
+    eng = HydroEngine(len(ec.STATE), DEV, ec.RHO, ec.G)
+    eng.set_params(ec.PARAMS)
+    out = eng.step_wrench_tiled(tiled(ec.STATE), len(ec.STATE), ec.DT, prev=tiled(ec.PREV))
+    o = scenes.from_tiled(out.cpu().numpy(), len(ec.STATE))
+    assert np.array_equal(o[:, :3], f) and np.array_equal(o[:, 3:], t)
+    eng.close()
