@@ -242,6 +242,53 @@ def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int 
             "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
 
 
+def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 13):
+    """The simulator-facing entry (hydro_step_wrench_aos: (N,3)/(N,4)/(N,6) tensors in, forces/torques
+    out, previous velocity kept in the engine): 168 algorithmic bytes per body-step."""
+    sc = build_scene("c4", n, seed)
+    reps = []
+    for r in range(sets):
+        idx = np.roll(np.arange(sc.n), r * 97)
+        e = HydroEngine(sc.n, dev, sc.rho, sc.g)
+        e.set_params(sc.params[idx]); e.set_prev_velocity(sc.prev[idx])
+        st = sc.state[idx]
+        reps.append((e, torch.from_numpy(np.ascontiguousarray(st[:, 0:3])).to(dev),
+                     torch.from_numpy(np.ascontiguousarray(st[:, [6, 3, 4, 5]])).to(dev),
+                     torch.from_numpy(np.ascontiguousarray(st[:, 7:13])).to(dev),
+                     torch.empty((sc.n, 3), device=dev), torch.empty((sc.n, 3), device=dev)))
+
+    def step(k):
+        e, pos, q, vel, f, t = reps[k % sets]
+        e.step_wrench_aos(pos, q, vel, sc.dt, forces=f, torques=t)
+    with torch.cuda.stream(stream):
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 0.15:
+            step(k); k += 1
+            if k % 64 == 0:
+                stream.synchronize()
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(steps):
+            step(k)
+        e1.record(stream); stream.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    for r in reps:
+        r[0].close()
+    return {"n": sc.n, "entry_point": "hydro_step_wrench_aos", "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
+            "algorithmic_gbs": sc.n * 168 / (us * 1e-6) / 1e9, "bytes_per_body_step": 168}
+
+
+def closed_loop_rate(kind: str, n: int, steps: int = 4096):
+    """Wrench + integrator ping-pong replayed from a HIP graph (simulate.ClosedLoopSim); RTF as
+    benchmark_rtf.py defines it (sim time / wall time)."""
+    from silver2_isaacsim_amd.simulate import ClosedLoopSim
+    sim = ClosedLoopSim(build_scene(kind, n, 17))
+    r = sim.measure_rtf(steps, graph_steps=64)
+    sim.close()
+    return {"n": n, "mode": "hipGraph x64 (wrench_tiled + integrate_tiled)", **r}
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected
     separately; FETCH_SIZE doubled per the gfx950 correction).  None when not measured."""
@@ -265,6 +312,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--bodies-per-lane", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU gets the workload's bodies (default); strong: the workload's bodies are "
+                         "block-partitioned over the GPUs (BASELINE config 4: 262 144 bodies over 8 GPUs)")
     ap.add_argument("--spinup-seconds", type=float, default=1.0,
                     help="untimed run of the step loop before the W warm-up steps (GPU clock ramp)")
     ap.add_argument("--layout", default="tiled", choices=["tiled", "soa"],
@@ -290,7 +340,12 @@ def main():
     n = args.bodies or n_default
     if n != n_default:
         desc = f"{desc} [overridden: {n} bodies/GPU]"
-    sc = build_scene(kind, n, seed=5 + rank)
+    if args.scaling == "strong" and world > 1:
+        full = build_scene(kind, n, seed=5)                      # same scene on every rank ...
+        sc = full.shard(rank, world)                             # ... each keeps its contiguous block
+        desc = f"{desc} [strong scaling: {n} bodies over {world} GPUs]"
+    else:
+        sc = build_scene(kind, n, seed=5 + rank)
     replicas = [Replica(sc, coeff, dev, roll=r * 131071, layout=args.layout) for r in range(args.scenes)]
     if args.bodies_per_lane:
         for r in replicas:
@@ -299,7 +354,10 @@ def main():
 
     spin_up(replicas, stream, args.spinup_seconds)
     wall, ev_ms = timed_steps(replicas, args.steps, args.warmup, stream, world)
-    body_steps = sc.n * args.steps * world
+    # bodies on all ranks (shards differ by at most one body under strong scaling)
+    n_all = torch.tensor([float(sc.n)], dtype=torch.float64, device=hd.collective_device(dev) if world > 1 else "cpu")
+    hd.all_reduce_sum_(n_all)
+    body_steps = float(n_all.item()) * args.steps
     value = body_steps / wall
     kernel_us = ev_ms * 1e3 / args.steps
     bpb = BYTES_PER_BODY[coeff]
@@ -320,7 +378,7 @@ def main():
         out = {
             "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "bodies_per_gpu": sc.n, "coefficients": coeff,
                        "scene_replicas_per_gpu": args.scenes, "bytes_per_body_step": bpb,
@@ -365,6 +423,11 @@ def main():
             ex["f16_4194304"] = quick_rate("c5", 4194304, "f16", dev, stream, steps=50, sets=2)
             ex["plain_soa_c5_1048576"] = quick_rate("c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
             ex["plain_soa_f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
+            try:
+                ex["aos_entry_1048576"] = aos_rate(1048576, dev, stream)
+                ex["closed_loop_c2_4096"] = closed_loop_rate("c2", 4096)
+            except Exception as e:                          # noqa: BLE001
+                ex["aos_or_closed_loop_error"] = repr(e)
             out["extras"] = ex
         print(json.dumps(out), flush=True)
 
