@@ -15,9 +15,12 @@ Parity pinning: `tests/golden/make_golden.py` executes the reference's own
 functions (identity-`njit` stub; Numba itself is not installed in the build
 container) on seeded inputs and commits inputs+outputs as `.npz` fixtures;
 `tests/test_oracle_golden.py` checks this module against them to <=1e-12.
-The behaviour-level epilogue (A13-A15) and the C1 trajectory have no
-executable reference here (torch/omni code) and are pinned only by the
-survey's K1-K5 known-answer vectors.
+The behaviour-level epilogue (A13-A16) is pinned the same way: the generator
+executes the reference's own `_apply_behavior` (hydrodynamics_behavior.py:176-238,
+float64 torch tensors, Kit-only imports replaced by empty shells) and stores the
+net force / torque it hands to the simulator; the survey's K1-K5 known-answer
+vectors are checked too.  Only the C1 trajectory's
+integrator (PhysX in the reference) is this repo's own.
 
 Documented completion: the reference's
 `calculate_pressure_and_area` has no return value when `speed <= 1e-6`

@@ -12,9 +12,20 @@ in `sys.modules`; the reference's function bodies are plain NumPy and execute
 in float64.  `fastmath=True` only licenses re-association (~1e-15).  Nothing is
 written into /root/reference (`sys.dont_write_bytecode`).
 
+The behaviour-level epilogue is executed too: `hydrodynamics_behavior.py` is
+imported with empty import shells for the Kit-only packages it names at module
+level (omni, carb, pxr, isaacsim, warp - attribute access returns a dummy,
+nothing of Kit is emulated), an instance is made with `object.__new__` (no
+`on_init`), given an in-memory body view, the reference's Numba calculator and
+float64 torch tensors, and the reference's own `_apply_behavior(dt)`
+(hydrodynamics_behavior.py:176-238: wxyz->xyzw, finite-difference acceleration,
+lever-arm torques, sum, clamp) runs unchanged; what it hands to
+`apply_forces_and_torques_at_pos` is stored as `net_force` / `net_torque`.
+
 What each fixture holds: fp32-exact inputs (state, acceleration or previous
-velocity + dt, params, rho, g) and the reference's nine outputs per body
-(`solve_hydrodynamics`, numba_hydrodynamics.py:256-314) in float64.
+velocity + dt, params, rho, g), the reference's nine outputs per body
+(`solve_hydrodynamics`, numba_hydrodynamics.py:256-314) and the net wrench of
+the reference's `_apply_behavior`, all float64.
 
 N1 completion: for a wet body with speed <= 1e-6 the reference's
 `calculate_pressure_and_area` returns None and `solve_hydrodynamics` raises
@@ -39,6 +50,38 @@ import numpy as np  # noqa: E402
 REFERENCE_SCRIPTS = "/root/reference/src/scripts"
 
 
+class _Anything:
+    """Import shell value: any attribute, any call; as a decorator it returns the function unchanged."""
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not isinstance(a[0], _Anything) and not k:
+            return a[0]
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+    def __iter__(self):
+        return iter(())
+
+
+class _ShellModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if name == "BehaviorScript":                     # must be subclassable
+            return type("BehaviorScript", (object,), {})
+        return _Anything()
+
+
+KIT_ONLY = ["carb", "omni", "omni.kit", "omni.kit.window", "omni.kit.window.property", "omni.physx", "omni.kit.scripting",
+            "omni.isaac", "omni.isaac.core", "omni.isaac.core.prims", "omni.isaac.core.simulation_context", "warp",
+            "isaacsim", "isaacsim.replicator", "isaacsim.replicator.behavior", "isaacsim.replicator.behavior.global_variables",
+            "isaacsim.replicator.behavior.utils", "isaacsim.replicator.behavior.utils.behavior_utils", "pxr"]
+
+
 def import_reference():
     stub = types.ModuleType("numba")
 
@@ -49,13 +92,19 @@ def import_reference():
 
     stub.njit = njit
     sys.modules["numba"] = stub
+    for name in KIT_ONLY:
+        shell = _ShellModule(name)
+        shell.__path__ = []
+        sys.modules[name] = shell
     sys.path.insert(0, REFERENCE_SCRIPTS)
     import physics.numba_hydrodynamics as ref_k                    # noqa: E402
     import physics.numba_hydrodynamics_wrapper as ref_w            # noqa: E402
-    return ref_k, ref_w
+    import physics.hydrodynamics_behavior as ref_b                 # noqa: E402
+    return ref_k, ref_w, ref_b
 
 
-REF_K, REF_W = import_reference()
+REF_K, REF_W, REF_B = import_reference()
+import torch  # noqa: E402
 
 
 def reference_body(state, accel, params, rho, g):
@@ -95,6 +144,65 @@ def reference_body(state, accel, params, rho, g):
     return comps, float(ratio), True
 
 
+class _View:
+    """In-memory stand-in for RigidPrimView: hands out the tensors, records what is applied."""
+
+    def __init__(self, p, q_wxyz, vel6):
+        self.p, self.q, self.v = p, q_wxyz, vel6
+        self.applied = None
+
+    def get_world_poses(self, clone=False):
+        return self.p, self.q
+
+    def get_velocities(self, clone=False):
+        return self.v
+
+    def apply_forces_and_torques_at_pos(self, forces=None, torques=None, positions=None, is_global=True):
+        self.applied = (forces.clone(), torques.clone())
+
+
+class _Calculator:
+    """The reference's Numba calculator behind the tensor interface the behavior expects
+    (8 tensors of shape (1,3)); N1 completion as in `reference_body`."""
+
+    def __init__(self, params, rho, g):
+        self.params, self.rho, self.g = params, rho, g
+        self.last = None
+
+    def calculate_hydrodynamic_forces(self, p, q, v, w, a, al):
+        state = np.concatenate([x[0].numpy() for x in (p, q, v, w)])
+        accel = np.concatenate([a[0].numpy(), al[0].numpy()])
+        comps, ratio, rest = reference_body(state, accel, self.params, self.rho, self.g)
+        self.last = (comps, ratio, rest)
+        return tuple(torch.from_numpy(comps[k].copy())[None, :] for k in range(8))
+
+
+def reference_behavior_wrench(state, prev, params, rho, g, dt):
+    """Net (force, torque) of ONE body exactly as the reference's `_apply_behavior` computes them,
+    in float64 (hydrodynamics_behavior.py:176-238 executed unchanged)."""
+    f64 = lambda x: torch.tensor(np.asarray(x, dtype=np.float64)[None, :])   # noqa: E731
+    s = np.asarray(state, dtype=np.float64)
+    obj = object.__new__(REF_B.HydrodynamicsBehavior)
+    obj._device = "cpu"
+    obj._rigid_prim_view = _View(f64(s[0:3]), f64(s[[6, 3, 4, 5]]), f64(s[7:13]))     # simulator order: wxyz
+    obj._hydro_calculator = _Calculator(params, rho, g)
+    obj._mass = torch.tensor(float(params[10]), dtype=torch.float64)
+    obj._last_linear_velocity = f64(prev[0:3])
+    obj._last_angular_velocity = f64(prev[3:6])
+    obj._apply_behavior(float(dt))
+    f, t = obj._rigid_prim_view.applied
+    assert torch.equal(obj._last_linear_velocity, f64(s[7:10]))                      # :237-238
+    return f[0].numpy(), t[0].numpy()
+
+
+def reference_behavior_batch(state, prev, params, rho, g, dt):
+    n = state.shape[0]
+    net_f, net_t = np.zeros((n, 3)), np.zeros((n, 3))
+    for i in range(n):
+        net_f[i], net_t[i] = reference_behavior_wrench(state[i], prev[i], params[i], rho, g, dt)
+    return net_f, net_t
+
+
 def reference_batch(state, accel, params, rho, g):
     n = state.shape[0]
     comps = np.zeros((n, 8, 3))
@@ -114,11 +222,12 @@ def save_scene_fixture(name, scene, idx):
     state, prev, params = scene.state[idx], scene.prev[idx], scene.params[idx]
     accel = accel_from_prev(scene)[idx]
     comps, ratio, rest = reference_batch(state, accel, params, scene.rho, scene.g)
+    net_f, net_t = reference_behavior_batch(state, prev, params, scene.rho, scene.g, scene.dt)
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, index=np.asarray(idx, dtype=np.int64), state=state, prev=prev,
                         params=params, rho=np.float64(scene.rho), g=np.float64(scene.g),
                         dt=np.float64(scene.dt), components=comps, ratio=ratio, rest_completed=rest,
-                        scene_n=np.int64(scene.n))
+                        net_force=net_f, net_torque=net_t, scene_n=np.int64(scene.n))
     print(f"{name}: {len(idx)} bodies of {scene.n}, rest-completed {int(rest.sum())}, "
           f"dry {int((ratio == 0).sum())}, full {int((ratio == 1).sum())} -> {os.path.getsize(path)} B")
 
@@ -159,9 +268,15 @@ def known_answer_cases():
 def save_known_answers():
     names, state, accel, params = known_answer_cases()
     comps, ratio, rest = reference_batch(state, accel, params, 1025.0, 9.81)
+    dt = 1.0 / 60.0
+    prev = state[:, 7:13] - accel * dt               # so that (v - v_last)/dt reproduces the listed acceleration
+    net_f, net_t = reference_behavior_batch(state, prev, params, 1025.0, 9.81, dt)
     path = os.path.join(HERE, "kat.npz")
-    np.savez_compressed(path, names=np.array(names), state=state, accel=accel, params=params,
-                        rho=np.float64(1025.0), g=np.float64(9.81), components=comps, ratio=ratio)
+    np.savez_compressed(path, names=np.array(names), state=state, accel=accel, params=params, prev=prev, dt=np.float64(dt),
+                        rho=np.float64(1025.0), g=np.float64(9.81), components=comps, ratio=ratio,
+                        net_force=net_f, net_torque=net_t)
+    for n_, f_, t_ in zip(names, net_f, net_t):
+        print(f"  {n_}: net_F {f_} net_T {t_}")
     for n_, r_ in zip(names, ratio):
         print(f"  {n_}: ratio {r_!r}")
     print(f"kat: {len(names)} cases -> {os.path.getsize(path)} B")

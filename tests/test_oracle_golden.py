@@ -2,8 +2,9 @@
 
 tests/golden/*.npz were produced by tests/golden/make_golden.py, which executes the
 reference's own functions (numba_hydrodynamics.py / numba_hydrodynamics_wrapper.py) on
-seeded fp32-exact inputs.  The K1-K5 behaviour-level numbers (net force / torque / clamp)
-are the known-answer vectors recorded in SURVEY.md section 8c.
+seeded fp32-exact inputs.  The same script executes the reference's `_apply_behavior` and stores its
+net wrench; the K1-K5 behaviour-level numbers (net force / torque / clamp) recorded in SURVEY.md
+section 8c are checked as well.
 """
 import numpy as np
 import pytest
@@ -59,6 +60,20 @@ def test_c_wrench_equals_numpy_wrench(name, native_built):
     f2, t2, _ = ho.step_wrench(fx["state"], fx["prev"], fx["params"], rho, g, dt)
     err = ho.wrench_error(f, t, f2, t2, fx["params"], rho, g)
     assert err.max() < 1e-9      # two fp64 evaluation orders; the arm x drag cancellation amplifies 1e-16
+
+
+@pytest.mark.parametrize("name", ["kat"] + SCENE_FIXTURES)
+def test_fused_oracle_matches_the_reference_behavior_script(name, native_built):
+    """`net_force` / `net_torque` in the fixtures are what the reference's own `_apply_behavior`
+    (hydrodynamics_behavior.py:176-238, executed unchanged in float64) hands to the simulator:
+    quaternion reorder, finite-difference acceleration, lever arms, sum, clamp - A13-A16."""
+    fx = load_golden(name)
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    f, t, _ = ho.step_wrench(fx["state"], fx["prev"], fx["params"], rho, g, dt)
+    assert ho.wrench_error(f, t, fx["net_force"], fx["net_torque"], fx["params"], rho, g).max() < 1e-9   # fp64 vs fp64; the lever-arm cancellation amplifies 1e-16
+    fc, tc = c_oracle.wrench(fx["state"].astype(np.float32), fx["prev"].astype(np.float32), fx["params"].astype(np.float32), rho, g, dt)
+    tol = 1e-9 if name != "kat" else 1e-5          # the C entry takes fp32 inputs; K1-K5 inputs are not fp32-exact
+    assert ho.wrench_error(fc, tc, fx["net_force"], fx["net_torque"], fx["params"], rho, g).max() < tol
 
 
 # ---- K1-K5: behaviour-level known answers (SURVEY.md 8c) -------------------------------

@@ -47,6 +47,8 @@ def test_fused_wrench_matches_oracle_on_fixtures(name, vec, native_built):
     err = ho.wrench_error(f, t, rf, rt, fx["params"], rho, g)
     assert np.isfinite(f).all() and np.isfinite(t).all()
     assert err.max() <= GATE, f"{name} vec={vec}: {err.max():.3e}"
+    # ... and directly against what the reference's own _apply_behavior produced (fixture)
+    assert ho.wrench_error(f, t, fx["net_force"], fx["net_torque"], fx["params"], rho, g).max() <= GATE
     dry = aux["ratio"] == 0.0
     assert np.all(f[dry] == 0.0) and np.all(t[dry] == 0.0)
 
