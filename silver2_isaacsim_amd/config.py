@@ -131,9 +131,17 @@ def resolve_overrides(prim_name: str, data: Mapping[str, Any] | None) -> dict[st
     return out
 
 
+def _usd_float(value) -> float:
+    """The schema's attributes are Sdf.ValueTypeNames.Float (hydrodynamics_behavior.py:30-45):
+    32-bit.  Round like USD does, so that e.g. the JSON's 9.81 and an authored 9.81 compare equal."""
+    import struct
+    return struct.unpack("<f", struct.pack("<f", float(value)))[0]
+
+
 class AttributeStore:
     """Dict-backed stand-in for a USD prim's exposed attributes, used when `pxr`
-    is absent (tests, headless drivers).  Keys are full attribute names."""
+    is absent (tests, headless drivers).  Keys are full attribute names; values are
+    held at float32 precision like USD `float` attributes."""
 
     def __init__(self, name: str, path: str | None = None, rigid_body: bool = True,
                  initial: Mapping[str, float] | None = None):
@@ -143,13 +151,13 @@ class AttributeStore:
         self._attrs: dict[str, float] = {}
         if initial:
             for k, v in initial.items():
-                self._attrs[full_attr_name(k)] = float(v)
+                self._attrs[full_attr_name(k)] = _usd_float(v)
 
     def GetName(self) -> str:               # noqa: N802 (USD naming)
         return self._name
 
     def create(self, full_name: str, default: float) -> None:
-        self._attrs.setdefault(full_name, float(default))
+        self._attrs.setdefault(full_name, _usd_float(default))
 
     def has(self, full_name: str) -> bool:
         return full_name in self._attrs
@@ -157,7 +165,7 @@ class AttributeStore:
     def set(self, full_name: str, value: float) -> bool:
         if full_name not in self._attrs:
             return False
-        self._attrs[full_name] = float(value)
+        self._attrs[full_name] = _usd_float(value)
         return True
 
     def get(self, full_name: str) -> float:

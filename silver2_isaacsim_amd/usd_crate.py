@@ -311,3 +311,9 @@ def params_rows(table: dict, default_mass: float = 1.0):
                      t["linearAddedMassCoefficient"], t["angularAddedMassCoefficient"], t.get("mass", default_mass)])
     first = {**cfg.SCHEMA_DEFAULTS, **(table[prims[0]] if prims else {})}
     return prims, np.asarray(rows, dtype=np.float32), float(first["waterDensity"]), float(first["gravity"])
+
+
+if __name__ == "__main__":                       # python -m silver2_isaacsim_amd.usd_crate scene.usd
+    import json
+    import sys
+    print(json.dumps(hydrodynamics_table(sys.argv[1]), indent=1, sort_keys=True))

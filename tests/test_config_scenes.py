@@ -55,9 +55,10 @@ def test_attribute_store():
     name = cfg.full_attr_name("gravity")
     assert not prim.set(name, 1.0)                      # not created yet -> refused, like an invalid USD attr
     prim.create(name, 9.81)
-    assert prim.get(name) == 9.81 and prim.set(name, 3.7) and prim.get(name) == 3.7
+    f32 = lambda x: float(np.float32(x))                  # noqa: E731  (USD float attributes are 32-bit)
+    assert prim.get(name) == f32(9.81) and prim.set(name, 3.7) and prim.get(name) == f32(3.7)
     prim.create(name, 9.81)                             # create never clobbers an authored value
-    assert prim.get(name) == 3.7 and prim.GetName() == "Coxa_1" and prim.path == "/World/Coxa_1"
+    assert prim.get(name) == f32(3.7) and prim.GetName() == "Coxa_1" and prim.path == "/World/Coxa_1"
 
 
 # ---------------------------------------------------------------- scenes

@@ -170,3 +170,23 @@ def test_calculator_batched_and_fused(native_built):
     with pytest.raises(ValueError):
         HipHydrodynamicsWrapper(1, 1, 1, 1.2, 0.8, 300, 150, [1025.0, 1000.0], 9.81, 0.05, 0.02, 1.0)
     w.close()
+
+
+def test_headless_buoy_demo(tmp_path, native_built):
+    """The reference's validation demo end to end: USD table -> 20 behaviors -> one launch per step ->
+    RTF meter + velocity CSV; the buoy settles at its float height."""
+    import csv
+    import importlib.util
+    import os
+    from conftest import REPO
+    hb.REGISTRY.clear()
+    spec = importlib.util.spec_from_file_location("buoy_demo", os.path.join(REPO, "examples", "buoy_bobbing_headless.py"))
+    demo = importlib.util.module_from_spec(spec); spec.loader.exec_module(demo)
+    out = demo.main(["--steps", "900", "--out", str(tmp_path)])
+    z = out["z"]
+    float_height = 1.5 - demo.BUOY_MASS / 1025.0                 # centre height of a 1x1x3 m box floating upright
+    assert z[0] > float_height and abs(z[-1] - float_height) < 0.05 and z.min() > 0.0
+    assert out["apply_calls"] == 900                             # 20 prims, one batched apply per step
+    assert out["stats"]["physics_steps"] == 900 and out["stats"]["rtf"] > 1.0
+    rows = list(csv.reader(open(out["csv"])))
+    assert len(rows) == 901 and rows[0][1] == "z_position" and float(rows[-1][1]) == pytest.approx(z[-1], abs=1e-5)
