@@ -1,16 +1,17 @@
 // gfx950 (MI355X / CDNA4) kernels and C ABI of libhydro.so - see include/hydro.h.
 //
-// Every kernel is elementwise per rigid body and HBM-bound (about 400 VALU
-// instructions against 144 B per body-step): no MFMA anywhere.  What matters is
-//   * struct-of-arrays state so that each wave-instruction reads a contiguous run
-//     of one field (4/8/16 B per lane = 256 B / 512 B / 1 KiB per wave64 request);
-//   * all of a body's ~30 loads issued before the first use, so a wave has its
-//     whole working set in flight at once (the kernels are single-pass, latency is
-//     hidden by occupancy: 4-8 waves per SIMD);
+// Every kernel is elementwise per rigid body and HBM-bound (about 560 VALU instructions
+// against 136-144 B per body-step): no MFMA anywhere.  What matters is
+//   * layouts in which each wave-instruction reads one contiguous 256-B run of one field
+//     (plain SoA) and - better - in which the ~28 runs a wavefront needs form three contiguous
+//     records (tiled SoA, the native layout): DRAM pages are consumed whole;
+//   * all of a body's 28 loads issued before the first use, so a wave has its whole working
+//     set in flight at once (single-pass kernels, latency hidden by 6 waves per SIMD);
+//   * non-temporal accesses for scenes larger than the caches: every byte is touched once per step;
 //   * nothing re-read and nothing written but the wrench (24 B per body).
-// The array-of-structs entry point (the simulator's tensor layout) stages the
-// transposition through LDS; the kinetic-energy reduction uses wave64 shuffles,
-// LDS across the block's four waves and a fixed-order second stage.
+// The array-of-structs entry points (the simulator's tensor layout) stage the transposition
+// through LDS; the kinetic-energy reduction uses wave64 shuffles, LDS across the block's four
+// waves and a fixed-order second stage.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
