@@ -403,6 +403,15 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extras:
+            # median of 5 runs (each 200 steps after 20 warm-up steps), same replicas
+            runs = []
+            for _ in range(5):
+                _, ms5 = timed_steps(replicas, 200, 20, stream, 1)
+                runs.append(ms5 * 1e3 / 200)
+            runs.sort()
+            out["roofline"]["kernel_us_5x200_runs"] = runs
+            out["roofline"]["kernel_us_median_of_5"] = runs[2]
+            out["roofline"]["frac_median_of_5"] = sc.n * bpb / (runs[2] * 1e-6) / 1e9 / HBM_PEAK_GBS
             for r in replicas:
                 r.engine.close()
             replicas = []
