@@ -279,14 +279,16 @@ def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 1
             "algorithmic_gbs": sc.n * 168 / (us * 1e-6) / 1e9, "bytes_per_body_step": 168}
 
 
-def closed_loop_rate(kind: str, n: int, steps: int = 4096):
+def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True):
     """Wrench + integrator ping-pong replayed from a HIP graph (simulate.ClosedLoopSim); RTF as
-    benchmark_rtf.py defines it (sim time / wall time)."""
+    benchmark_rtf.py defines it (sim time / wall time).  fused: one kernel per physics step
+    (hydro_step_fused_tiled) instead of two."""
     from silver2_isaacsim_amd.simulate import ClosedLoopSim
-    sim = ClosedLoopSim(build_scene(kind, n, 17))
+    sim = ClosedLoopSim(build_scene(kind, n, 17), fused=fused)
     r = sim.measure_rtf(steps, graph_steps=64)
     sim.close()
-    return {"n": n, "mode": "hipGraph x64 (wrench_tiled + integrate_tiled)", **r}
+    mode = "hipGraph x64 (hydro_step_fused_tiled)" if fused else "hipGraph x64 (wrench_tiled + integrate_tiled)"
+    return {"n": n, "mode": mode, **r}
 
 
 def load_traffic(workload: str):
@@ -435,6 +437,9 @@ def main():
             try:
                 ex["aos_entry_1048576"] = aos_rate(1048576, dev, stream)
                 ex["closed_loop_c2_4096"] = closed_loop_rate("c2", 4096)
+                ex["closed_loop_c2_4096_unfused"] = closed_loop_rate("c2", 4096, fused=False)
+                ex["closed_loop_c2_262144"] = closed_loop_rate("c2", 262144, steps=1024)
+                ex["closed_loop_c2_262144_unfused"] = closed_loop_rate("c2", 262144, steps=1024, fused=False)
             except Exception as e:                          # noqa: BLE001
                 ex["aos_or_closed_loop_error"] = repr(e)
             out["extras"] = ex

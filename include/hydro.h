@@ -164,6 +164,16 @@ int hydro_integrate_tiled(hydro_t *h, int64_t n, const float *state_in, int64_t 
                           const float *wrench, int64_t wrench_tile_stride, float dt,
                           float *state_out, int64_t out_tile_stride, void *stream);
 
+/* Wrench + integrator fused into one pass over tiled buffers (closed-loop runs): the state is read
+ * once and the wrench does not go through memory unless `wrench` is non-NULL.  `prev` is normally the
+ * previous state buffer + 7 * 64 (tile stride 13 * 64); `state_out` may alias that previous-state
+ * buffer (ping-pong) but not `state`.  Same arithmetic, same bits as hydro_step_wrench_tiled followed
+ * by hydro_integrate_tiled. */
+int hydro_step_fused_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
+                           const float *prev, int64_t prev_tile_stride, float dt,
+                           float *state_out, int64_t out_tile_stride,
+                           float *wrench, int64_t wrench_tile_stride, void *stream);
+
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
  * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1). */
 int hydro_set_tuning(hydro_t *h, int bodies_per_lane, int block_threads, int non_temporal);

@@ -184,6 +184,25 @@ class HydroEngine:
             out.data_ptr(), nat.WRENCH_FIELDS * nat.TILE, self._stream(stream)))
         return out
 
+    def step_fused_tiled(self, state: torch.Tensor, prev_state: torch.Tensor, n: int, dt: float,
+                         state_out: torch.Tensor | None = None, wrench: torch.Tensor | None = None, stream=None):
+        """Wrench + integrator in one kernel.  `prev_state` (tiles,13,64) supplies the previous velocity;
+        `state_out` defaults to `prev_state` itself (ping-pong: the old buffer receives the new state)."""
+        self._check_tiled(state, nat.STATE_FIELDS, n)
+        self._check_tiled(prev_state, nat.STATE_FIELDS, n)
+        if state_out is None:
+            state_out = prev_state
+        self._check_tiled(state_out, nat.STATE_FIELDS, n)
+        w_ptr, w_stride = None, 0
+        if wrench is not None:
+            self._check_tiled(wrench, nat.WRENCH_FIELDS, n)
+            w_ptr, w_stride = wrench.data_ptr(), nat.WRENCH_FIELDS * nat.TILE
+        st = nat.STATE_FIELDS * nat.TILE
+        self._check(self._lib.hydro_step_fused_tiled(
+            self._h, n, state.data_ptr(), st, prev_state.data_ptr() + 7 * nat.TILE * 4, st, float(dt),
+            state_out.data_ptr(), st, w_ptr, w_stride, self._stream(stream)))
+        return state_out
+
     def integrate_tiled(self, state_in: torch.Tensor, wrench: torch.Tensor, n: int, dt: float,
                         state_out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
         if state_out is None:

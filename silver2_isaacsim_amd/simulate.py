@@ -4,8 +4,9 @@ buffers in the tiled layout, optionally captured into a HIP graph (SURVEY.md 8f 
 The reference delegates integration to PhysX; this stand-in exists so that configs 1-5 can run for
 thousands of steps without a host round-trip and so that a real-time factor can be reported the way
 the reference's `benchmark_rtf.py` does (sim time / wall time).  One physics step =
-`hydro_step_wrench_tiled` (previous velocity read in place from the other state buffer) followed by
-`hydro_integrate_tiled`.  Both entry points are capture-safe, so K consecutive steps become ONE host
+`hydro_step_fused_tiled` (wrench + integrator in one kernel; `fused=False` runs
+`hydro_step_wrench_tiled` followed by `hydro_integrate_tiled`, same bits).  The previous velocity is
+read in place from the other state buffer.  All entry points are capture-safe, so K consecutive steps become ONE host
 call (`graph_steps`), which is what makes small scenes (launch-bound at ~8 us per ctypes launch) run
 at the kernels' own pace.
 """
@@ -21,8 +22,10 @@ from .engine import HydroEngine
 
 
 class ClosedLoopSim:
-    def __init__(self, scene: "scenes.Scene", device: int | str = 0, coeff_dtype: str | None = None):
+    def __init__(self, scene: "scenes.Scene", device: int | str = 0, coeff_dtype: str | None = None,
+                 fused: bool = True):
         self.scene = scene
+        self.fused = fused                                      # one kernel per step (hydro_step_fused_tiled)
         self.n = scene.n
         self.dt = scene.dt
         self.engine = HydroEngine(scene.n, device, scene.rho, scene.g)
@@ -41,8 +44,11 @@ class ClosedLoopSim:
     # one physics step on the current stream context
     def _step_once(self) -> None:
         e = self.engine
-        e.step_wrench_tiled(self.cur, self.n, self.dt, out=self.wrench, prev=self.old)
-        e.integrate_tiled(self.cur, self.wrench, self.n, self.dt, state_out=self.old)   # overwrite the old buffer
+        if self.fused:
+            e.step_fused_tiled(self.cur, self.old, self.n, self.dt)                     # new state lands in the old buffer
+        else:
+            e.step_wrench_tiled(self.cur, self.n, self.dt, out=self.wrench, prev=self.old)
+            e.integrate_tiled(self.cur, self.wrench, self.n, self.dt, state_out=self.old)   # overwrite the old buffer
         self.cur, self.old = self.old, self.cur
 
     def run_eager(self, steps: int) -> None:
