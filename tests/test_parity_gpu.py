@@ -532,3 +532,35 @@ def test_degenerate_inputs(native_built):
     o = scenes.from_tiled(out.cpu().numpy(), len(ec.STATE))
     assert np.array_equal(o[:, :3], f) and np.array_equal(o[:, 3:], t)
     eng.close()
+
+
+def test_engine_lifetime_does_not_leak(native_built):
+    """on_play / on_stop cycles create and drop engines: device memory must come back."""
+    fx = load_golden("c2")
+
+    def cycle():
+        eng = HydroEngine(1 << 20, DEV)                       # ~190 MB of engine-owned buffers each
+        eng.set_params(fx["params"][:1024])
+        eng.step_wrench(soa(fx["state"][:1024]), 1 / 60)
+        eng.close()
+    cycle()                                                    # one-time costs: code objects, allocator pools
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(30):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
+    # many small handles at once (one per prim in per-prim mode), independent results
+    engines = [HydroEngine(1, DEV) for _ in range(64)]
+    outs = []
+    for k, e in enumerate(engines):
+        e.set_params(fx["params"][k:k + 1])
+        outs.append(e.step_wrench(soa(fx["state"][k:k + 1]), float(fx["dt"]), prev=soa(fx["prev"][k:k + 1])))
+    torch.cuda.synchronize()
+    f, t = run_ext(fx["state"][:64], fx["prev"][:64], fx["params"][:64], float(fx["rho"]), float(fx["g"]), float(fx["dt"]))
+    got = torch.cat(outs, dim=1).cpu().numpy().T
+    assert np.array_equal(got[:, :3], f) and np.array_equal(got[:, 3:], t)
+    for e in engines:
+        e.close()
+    e.close()                                                  # double close is harmless
