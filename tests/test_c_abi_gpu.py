@@ -1,0 +1,45 @@
+"""The C ABI used from plain C (no Python, no torch on the product side): examples/c_abi_demo.c is
+compiled against include/hydro.h + libhydro.so and its output compared with the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+from oracle import hydro_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plain_c_host_program(tmp_path, native_built):
+    exe = str(tmp_path / "c_abi_demo")
+    lib_dir = os.path.join(REPO, "silver2_isaacsim_amd", "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(REPO, "examples", "c_abi_demo.c"),
+           "-I", os.path.join(rocm, "include"), "-I", os.path.join(REPO, "include"),
+           "-L", lib_dir, "-lhydro", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+           f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    fx = load_golden("c4")
+    n = 1000                                      # not a multiple of 64: ragged last tile
+    blob = str(tmp_path / "bodies.bin")
+    with open(blob, "wb") as f:
+        f.write(struct.pack("<q", n))
+        f.write(np.ascontiguousarray(fx["state"][:n], np.float32).tobytes())
+        f.write(np.ascontiguousarray(fx["prev"][:n], np.float32).tobytes())
+        f.write(np.ascontiguousarray(fx["params"][:n], np.float32).tobytes())
+        f.write(struct.pack("<f", float(fx["dt"])))
+    run = subprocess.run([exe, blob], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "HYDRO_E_STATE" not in run.stdout and "parameters not set" in run.stderr      # the message of the provoked error
+    got = np.array([[float(x) for x in line.split()] for line in run.stdout.strip().splitlines()])
+    assert got.shape == (n, 6)
+    rho, g = float(fx["rho"]), float(fx["g"])
+    err = ho.wrench_error(got[:, :3], got[:, 3:], fx["net_force"][:n], fx["net_torque"][:n], fx["params"][:n], rho, g)
+    assert err.max() <= 1e-5
+    ke_line = [l for l in run.stderr.splitlines() if l.startswith("kinetic energy")][0]
+    lin = float(ke_line.split()[2])
+    assert lin == pytest.approx(ho.kinetic_energy(fx["state"][:n], fx["params"][:n])[0], rel=1e-8)
