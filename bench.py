@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=4, help="scene replicas stepped round-robin per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--extras-budget-seconds", type=float, default=150.0,
+                    help="secondary measurements are skipped once this much time has gone into them")
     ap.add_argument("--bodies-per-lane", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the workload's bodies (default); strong: the workload's bodies are "
@@ -401,47 +403,59 @@ def main():
         if traffic:
             out["roofline"]["traffic_source"] = traffic.get("source")
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline_leg(sc, _last_stepped(replicas, args.steps), args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline_leg(sc, _last_stepped(replicas, args.steps), args.cpu_seconds)
+            except Exception as e:                          # noqa: BLE001 - report, never lose the line
+                out["cpu_baseline"] = {"value": None, "unit": "body-steps/s", "cores": 1, "kind": "port",
+                                       "sample": "failed", "error": repr(e)}
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extras:
             # median of 5 runs (each 200 steps after 20 warm-up steps), same replicas
-            runs = []
-            for _ in range(5):
-                _, ms5 = timed_steps(replicas, 200, 20, stream, 1)
-                runs.append(ms5 * 1e3 / 200)
-            runs.sort()
-            out["roofline"]["kernel_us_5x200_runs"] = runs
-            out["roofline"]["kernel_us_median_of_5"] = runs[2]
-            out["roofline"]["frac_median_of_5"] = sc.n * bpb / (runs[2] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            try:
+                runs = []
+                for _ in range(5):
+                    _, ms5 = timed_steps(replicas, 200, 20, stream, 1)
+                    runs.append(ms5 * 1e3 / 200)
+                runs.sort()
+                out["roofline"]["kernel_us_5x200_runs"] = runs
+                out["roofline"]["kernel_us_median_of_5"] = runs[2]
+                out["roofline"]["frac_median_of_5"] = sc.n * bpb / (runs[2] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            except Exception as e:                          # noqa: BLE001
+                out["roofline"]["kernel_us_5x200_runs"] = repr(e)
             for r in replicas:
                 r.engine.close()
             replicas = []
             torch.cuda.empty_cache()
             ex = {}
-            ex["c2_4096"] = quick_rate("c2", 4096, "f32", dev, stream, steps=200)
-            ex["c3_19456"] = quick_rate("c3", 19456, "f32", dev, stream, steps=200)
-            ex["c4_shard_32768"] = quick_rate("c4", 32768, "f32", dev, stream, steps=200)
-            for key, (kind, nn) in {"c2_4096_graph": ("c2", 4096), "c3_19456_graph": ("c3", 19456),
-                                    "c4_shard_32768_graph": ("c4", 32768)}.items():
+
+            t_extras = time.perf_counter()
+
+            def guarded(key, fn, *fa, **fk):
+                if time.perf_counter() - t_extras > args.extras_budget_seconds:
+                    ex[key] = {"skipped": "extras time budget"}
+                    return
                 try:
-                    ex[key] = graph_rate(kind, nn, "f32", dev, stream)
+                    ex[key] = fn(*fa, **fk)
                 except Exception as e:                      # noqa: BLE001 - extras never break the headline
                     ex[key] = {"error": repr(e)}
-            ex["c4_262144"] = quick_rate("c4", 262144, "f32", dev, stream, steps=100)
-            ex["c5_f32_1048576"] = quick_rate("c4", 1048576, "f32", dev, stream, steps=100)
-            ex["f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2)
-            ex["f16_4194304"] = quick_rate("c5", 4194304, "f16", dev, stream, steps=50, sets=2)
-            ex["plain_soa_c5_1048576"] = quick_rate("c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
-            ex["plain_soa_f32_4194304"] = quick_rate("c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
-            try:
-                ex["aos_entry_1048576"] = aos_rate(1048576, dev, stream)
-                ex["closed_loop_c2_4096"] = closed_loop_rate("c2", 4096)
-                ex["closed_loop_c2_4096_unfused"] = closed_loop_rate("c2", 4096, fused=False)
-                ex["closed_loop_c2_262144"] = closed_loop_rate("c2", 262144, steps=1024)
-                ex["closed_loop_c2_262144_unfused"] = closed_loop_rate("c2", 262144, steps=1024, fused=False)
-            except Exception as e:                          # noqa: BLE001
-                ex["aos_or_closed_loop_error"] = repr(e)
+            guarded("c2_4096", quick_rate, "c2", 4096, "f32", dev, stream, steps=200)
+            guarded("c3_19456", quick_rate, "c3", 19456, "f32", dev, stream, steps=200)
+            guarded("c4_shard_32768", quick_rate, "c4", 32768, "f32", dev, stream, steps=200)
+            guarded("c2_4096_graph", graph_rate, "c2", 4096, "f32", dev, stream)
+            guarded("c3_19456_graph", graph_rate, "c3", 19456, "f32", dev, stream)
+            guarded("c4_shard_32768_graph", graph_rate, "c4", 32768, "f32", dev, stream)
+            guarded("c4_262144", quick_rate, "c4", 262144, "f32", dev, stream, steps=100)
+            guarded("c5_f32_1048576", quick_rate, "c4", 1048576, "f32", dev, stream, steps=100)
+            guarded("f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2)
+            guarded("f16_4194304", quick_rate, "c5", 4194304, "f16", dev, stream, steps=50, sets=2)
+            guarded("plain_soa_c5_1048576", quick_rate, "c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
+            guarded("plain_soa_f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
+            guarded("aos_entry_1048576", aos_rate, 1048576, dev, stream)
+            guarded("closed_loop_c2_4096", closed_loop_rate, "c2", 4096)
+            guarded("closed_loop_c2_4096_unfused", closed_loop_rate, "c2", 4096, fused=False)
+            guarded("closed_loop_c2_262144", closed_loop_rate, "c2", 262144, steps=1024)
+            guarded("closed_loop_c2_262144_unfused", closed_loop_rate, "c2", 262144, steps=1024, fused=False)
             out["extras"] = ex
         print(json.dumps(out), flush=True)
 
