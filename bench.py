@@ -279,15 +279,17 @@ def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 1
             "algorithmic_gbs": sc.n * 168 / (us * 1e-6) / 1e9, "bytes_per_body_step": 168}
 
 
-def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True):
+def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, implicit_drag: bool = False):
     """Wrench + integrator ping-pong replayed from a HIP graph (simulate.ClosedLoopSim); RTF as
     benchmark_rtf.py defines it (sim time / wall time).  fused: one kernel per physics step
     (hydro_step_fused_tiled) instead of two."""
     from silver2_isaacsim_amd.simulate import ClosedLoopSim
-    sim = ClosedLoopSim(build_scene(kind, n, 17), fused=fused)
+    sim = ClosedLoopSim(build_scene(kind, n, 17), fused=fused, implicit_drag=implicit_drag)
     r = sim.measure_rtf(steps, graph_steps=64)
     sim.close()
     mode = "hipGraph x64 (hydro_step_fused_tiled)" if fused else "hipGraph x64 (wrench_tiled + integrate_tiled)"
+    if implicit_drag:
+        mode += ", implicit drag"
     return {"n": n, "mode": mode, **r}
 
 
@@ -454,6 +456,7 @@ def main():
             guarded("aos_entry_1048576", aos_rate, 1048576, dev, stream)
             guarded("closed_loop_c2_4096", closed_loop_rate, "c2", 4096)
             guarded("closed_loop_c2_4096_unfused", closed_loop_rate, "c2", 4096, fused=False)
+            guarded("closed_loop_c3_1024envs_implicit", closed_loop_rate, "c3", 19456, implicit_drag=True)
             guarded("closed_loop_c2_262144", closed_loop_rate, "c2", 262144, steps=1024)
             guarded("closed_loop_c2_262144_unfused", closed_loop_rate, "c2", 262144, steps=1024, fused=False)
             out["extras"] = ex

@@ -167,12 +167,15 @@ int hydro_integrate_tiled(hydro_t *h, int64_t n, const float *state_in, int64_t 
 /* Wrench + integrator fused into one pass over tiled buffers (closed-loop runs): the state is read
  * once and the wrench does not go through memory unless `wrench` is non-NULL.  `prev` is normally the
  * previous state buffer + 7 * 64 (tile stride 13 * 64); `state_out` may alias that previous-state
- * buffer (ping-pong) but not `state`.  Same arithmetic, same bits as hydro_step_wrench_tiled followed
- * by hydro_integrate_tiled. */
+ * buffer (ping-pong) but not `state`.  implicit_drag == 0: same arithmetic, same bits as
+ * hydro_step_wrench_tiled followed by hydro_integrate_tiled (explicit in every force).
+ * implicit_drag != 0: the drag part of the wrench (k_lin v, k_ang w) is taken at the new velocity,
+ * which is unconditionally stable where the explicit form needs |k| dt / m < 2 (light bodies with
+ * strong damping, e.g. the SILVER2 links at 120 Hz). */
 int hydro_step_fused_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
                            const float *prev, int64_t prev_tile_stride, float dt,
                            float *state_out, int64_t out_tile_stride,
-                           float *wrench, int64_t wrench_tile_stride, void *stream);
+                           float *wrench, int64_t wrench_tile_stride, int implicit_drag, void *stream);
 
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
  * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1). */

@@ -42,7 +42,7 @@ SIGNATURES = {
     "hydro_step_wrench_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
                                         c_void_p, c_int64, c_void_p]),
     "hydro_step_fused_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
-                                       c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+                                       c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "hydro_integrate_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
                                       c_void_p, c_int64, c_void_p]),
     "hydro_pack_state_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),

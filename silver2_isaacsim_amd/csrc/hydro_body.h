@@ -112,6 +112,7 @@ struct BodyOut {
     float armb_x, armb_y, armb_z;   // cob - p   (0 when dry)
     float armp_x, armp_y, armp_z;   // cop - p   (0 when dry)
     float dragarm_tx, dragarm_ty, dragarm_tz;   // (cop - p) x drag_force, cancellation-free form
+    float lin_k, ang_k;             // drag_force = lin_k * v, drag_torque = ang_k * w   (both <= 0; 0 when dry)
     bool wet;
 };
 
@@ -315,6 +316,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     o.am_tx = HYDRO_LIVE(r00 * tlx + r01 * tly + r02 * tlz);
     o.am_ty = HYDRO_LIVE(r10 * tlx + r11 * tly + r12 * tlz);
     o.am_tz = HYDRO_LIVE(r20 * tlx + r21 * tly + r22 * tlz);
+    o.lin_k = HYDRO_LIVE(lin_k); o.ang_k = HYDRO_LIVE(ang_k);
     o.armb_x = HYDRO_LIVE(armb_x); o.armb_y = HYDRO_LIVE(armb_y); o.armb_z = HYDRO_LIVE(armb_z);
     o.armp_x = HYDRO_LIVE(armp_x); o.armp_y = HYDRO_LIVE(armp_y); o.armp_z = HYDRO_LIVE(armp_z);
     const float ks = lin_k * speed;                                 // drag_force = ks * v_hat
@@ -323,7 +325,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     return o;
 }
 
-struct Wrench { float fx, fy, fz, tx, ty, tz; };
+struct Wrench { float fx, fy, fz, tx, ty, tz, scale; };   // scale = the clamp factor that was applied
 
 // A14-A15: lever-arm torques, sum, safety clamp (hydrodynamics_behavior.py:212-226).
 HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass)
@@ -340,6 +342,7 @@ HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass)
     Wrench w;
     w.fx = fx * scale; w.fy = fy * scale; w.fz = fz * scale;
     w.tx = tx * scale; w.ty = ty * scale; w.tz = tz * scale;
+    w.scale = scale;
     return w;
 }
 

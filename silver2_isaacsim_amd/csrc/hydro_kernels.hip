@@ -150,6 +150,28 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
     return hydro::assemble_wrench(o, mass);
 }
 
+// Same, also handing back the (clamped) linear / angular drag coefficients for the implicit integrator.
+__device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
+                                                       const float (&d)[3], const float (&c)[7], float mass,
+                                                       float rho, float g, float inv_dt, float& k_lin, float& k_ang)
+{
+    hydro::BodyIn b;
+    b.px = s[0]; b.py = s[1]; b.pz = s[2];
+    b.qx = s[3]; b.qy = s[4]; b.qz = s[5]; b.qw = s[6];
+    b.vx = s[7]; b.vy = s[8]; b.vz = s[9];
+    b.wx = s[10]; b.wy = s[11]; b.wz = s[12];
+    b.ax = (s[7] - pv[0]) * inv_dt; b.ay = (s[8] - pv[1]) * inv_dt; b.az = (s[9] - pv[2]) * inv_dt;
+    b.bx = (s[10] - pv[3]) * inv_dt; b.by = (s[11] - pv[4]) * inv_dt; b.bz = (s[12] - pv[5]) * inv_dt;
+    b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
+    b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
+    b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
+    const hydro::BodyOut o = hydro::solve_body(b, rho, g);
+    const hydro::Wrench w = hydro::assemble_wrench(o, mass);
+    k_lin = o.lin_k * w.scale;
+    k_ang = o.ang_k * w.scale;
+    return w;
+}
+
 // --------------------------------------------------------------------------
 // fused wrench, struct-of-arrays.  Each lane owns VEC consecutive bodies.
 // Algorithmic traffic per body: 52 B state + 24 B previous velocity + 44 B (30 B
@@ -602,13 +624,28 @@ struct IntArgs {
 };
 
 // semi-implicit Euler with gravity and box inertia for one body: s[13], wrench f[6] -> o[13]
+//
+// IMPLICIT (fused step only): the drag part of the wrench, k_lin * v and k_ang * w with k <= 0, is
+// taken at the NEW velocity (coefficients frozen at the old state):
+//     m (v' - v)/dt = (F - k_lin v) + k_lin v' + m g     =>   v' = (m v + dt (F - k_lin v + m g)) / (m - dt k_lin)
+// and likewise per principal axis for the angular part.  Unconditionally stable in the drag terms -
+// the explicit form needs |k| dt / m < 2, which the 0.45 kg SILVER2 links at 120 Hz violate (5.5).
+template <bool IMPLICIT>
 __device__ __forceinline__ void integrate_body(const float (&s)[HYDRO_STATE_FIELDS], const float (&f)[HYDRO_WRENCH_FIELDS],
                                                float m, float dx, float dy, float dz, float g, float dt,
-                                               float (&o)[HYDRO_STATE_FIELDS])
+                                               float k_lin, float k_ang, float (&o)[HYDRO_STATE_FIELDS])
 {
     const float inv_m = 1.0f / m;
-    // linear: semi-implicit Euler, gravity along -z
-    const float vx = s[7] + dt * (f[0] * inv_m), vy = s[8] + dt * (f[1] * inv_m), vz = s[9] + dt * (f[2] * inv_m - g);
+    float vx, vy, vz;
+    if constexpr (IMPLICIT) {
+        const float den = 1.0f / (m - dt * k_lin);
+        vx = (m * s[7] + dt * (f[0] - k_lin * s[7])) * den;
+        vy = (m * s[8] + dt * (f[1] - k_lin * s[8])) * den;
+        vz = (m * s[9] + dt * (f[2] - k_lin * s[9] - m * g)) * den;
+    } else {
+        // linear: semi-implicit Euler, gravity along -z
+        vx = s[7] + dt * (f[0] * inv_m); vy = s[8] + dt * (f[1] * inv_m); vz = s[9] + dt * (f[2] * inv_m - g);
+    }
     const float px = s[0] + dt * vx, py = s[1] + dt * vy, pz = s[2] + dt * vz;
     // angular, body frame: I w' = tau_b - w_b x (I w_b), box inertia
     const float qx = s[3], qy = s[4], qz = s[5], qw = s[6];
@@ -626,9 +663,16 @@ __device__ __forceinline__ void integrate_body(const float (&s)[HYDRO_STATE_FIEL
     const float tbx = r00 * f[3] + r10 * f[4] + r20 * f[5];
     const float tby = r01 * f[3] + r11 * f[4] + r21 * f[5];
     const float tbz = r02 * f[3] + r12 * f[4] + r22 * f[5];
-    const float nbx = wbx + dt * (tbx - (wby * (iz * wbz) - wbz * (iy * wby))) / ix;
-    const float nby = wby + dt * (tby - (wbz * (ix * wbx) - wbx * (iz * wbz))) / iy;
-    const float nbz = wbz + dt * (tbz - (wbx * (iy * wby) - wby * (ix * wbx))) / iz;
+    float nbx, nby, nbz;
+    if constexpr (IMPLICIT) {
+        nbx = (ix * wbx + dt * (tbx - k_ang * wbx - (wby * (iz * wbz) - wbz * (iy * wby)))) / (ix - dt * k_ang);
+        nby = (iy * wby + dt * (tby - k_ang * wby - (wbz * (ix * wbx) - wbx * (iz * wbz)))) / (iy - dt * k_ang);
+        nbz = (iz * wbz + dt * (tbz - k_ang * wbz - (wbx * (iy * wby) - wby * (ix * wbx)))) / (iz - dt * k_ang);
+    } else {
+        nbx = wbx + dt * (tbx - (wby * (iz * wbz) - wbz * (iy * wby))) / ix;
+        nby = wby + dt * (tby - (wbz * (ix * wbx) - wbx * (iz * wbz))) / iy;
+        nbz = wbz + dt * (tbz - (wbx * (iy * wby) - wby * (ix * wbx))) / iz;
+    }
     const float wx = r00 * nbx + r01 * nby + r02 * nbz;
     const float wy = r10 * nbx + r11 * nby + r12 * nbz;
     const float wz = r20 * nbx + r21 * nby + r22 * nbz;
@@ -656,7 +700,7 @@ __global__ void __launch_bounds__(kBlock) integrate_kernel(const IntArgs a)
     for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) s[k] = a.si[k][oi];
 #pragma unroll
     for (int k = 0; k < HYDRO_WRENCH_FIELDS; ++k) f[k] = a.w[k][ow];
-    integrate_body(s, f, a.mass[i], a.dims[0][i], a.dims[1][i], a.dims[2][i], a.g, a.dt, o);
+    integrate_body<false>(s, f, a.mass[i], a.dims[0][i], a.dims[1][i], a.dims[2][i], a.g, a.dt, 0.0f, 0.0f, o);
 #pragma unroll
     for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) a.so[k][oo] = o[k];
 }
@@ -673,7 +717,7 @@ struct FusedArgs {
     float dt;
 };
 
-template <bool HALF, bool NT>
+template <bool HALF, bool NT, bool IMPLICIT>
 __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArgs fa)
 {
     const TiledArgs& a = fa.t;
@@ -703,10 +747,13 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArg
         for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
         mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
     }
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
+    float k_lin = 0.0f, k_ang = 0.0f;
+    hydro::Wrench w;
+    if constexpr (IMPLICIT) w = body_wrench_k(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, k_lin, k_ang);
+    else w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
     const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
     float o[HYDRO_STATE_FIELDS];
-    integrate_body(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, o);
+    integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, k_lin, k_ang, o);
     const uint32_t oo = (__umul24(tile, fa.so_stride) + lane) * 4u;
 #pragma unroll
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(fa.so, oo + f * 256u), o[f]);
@@ -1195,7 +1242,7 @@ int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t 
 int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
                            const float* prev, int64_t prev_tile_stride, float dt,
                            float* state_out, int64_t out_tile_stride,
-                           float* wrench, int64_t wrench_tile_stride, void* stream)
+                           float* wrench, int64_t wrench_tile_stride, int implicit_drag, void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
@@ -1218,13 +1265,11 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
-    if (h->half_coeffs) {
-        if (nt) hipLaunchKernelGGL((step_fused_tiled_kernel<true, true>), grid, blk, 0, s, fa);
-        else hipLaunchKernelGGL((step_fused_tiled_kernel<true, false>), grid, blk, 0, s, fa);
-    } else {
-        if (nt) hipLaunchKernelGGL((step_fused_tiled_kernel<false, true>), grid, blk, 0, s, fa);
-        else hipLaunchKernelGGL((step_fused_tiled_kernel<false, false>), grid, blk, 0, s, fa);
-    }
+#define HYDRO_FUSED(HALF, NT) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true>), grid, blk, 0, s, fa); \
+                                   else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false>), grid, blk, 0, s, fa); } while (0)
+    if (h->half_coeffs) { if (nt) HYDRO_FUSED(true, true); else HYDRO_FUSED(true, false); }
+    else { if (nt) HYDRO_FUSED(false, true); else HYDRO_FUSED(false, false); }
+#undef HYDRO_FUSED
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }

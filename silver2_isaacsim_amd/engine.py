@@ -185,7 +185,8 @@ class HydroEngine:
         return out
 
     def step_fused_tiled(self, state: torch.Tensor, prev_state: torch.Tensor, n: int, dt: float,
-                         state_out: torch.Tensor | None = None, wrench: torch.Tensor | None = None, stream=None):
+                         state_out: torch.Tensor | None = None, wrench: torch.Tensor | None = None,
+                         implicit_drag: bool = False, stream=None):
         """Wrench + integrator in one kernel.  `prev_state` (tiles,13,64) supplies the previous velocity;
         `state_out` defaults to `prev_state` itself (ping-pong: the old buffer receives the new state)."""
         self._check_tiled(state, nat.STATE_FIELDS, n)
@@ -200,7 +201,7 @@ class HydroEngine:
         st = nat.STATE_FIELDS * nat.TILE
         self._check(self._lib.hydro_step_fused_tiled(
             self._h, n, state.data_ptr(), st, prev_state.data_ptr() + 7 * nat.TILE * 4, st, float(dt),
-            state_out.data_ptr(), st, w_ptr, w_stride, self._stream(stream)))
+            state_out.data_ptr(), st, w_ptr, w_stride, int(bool(implicit_drag)), self._stream(stream)))
         return state_out
 
     def integrate_tiled(self, state_in: torch.Tensor, wrench: torch.Tensor, n: int, dt: float,

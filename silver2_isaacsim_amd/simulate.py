@@ -23,7 +23,10 @@ from .engine import HydroEngine
 
 class ClosedLoopSim:
     def __init__(self, scene: "scenes.Scene", device: int | str = 0, coeff_dtype: str | None = None,
-                 fused: bool = True):
+                 fused: bool = True, implicit_drag: bool = False):
+        if implicit_drag and not fused:
+            raise ValueError("implicit drag needs the fused step (the drag coefficients never leave the kernel)")
+        self.implicit_drag = implicit_drag
         self.scene = scene
         self.fused = fused                                      # one kernel per step (hydro_step_fused_tiled)
         self.n = scene.n
@@ -45,7 +48,7 @@ class ClosedLoopSim:
     def _step_once(self) -> None:
         e = self.engine
         if self.fused:
-            e.step_fused_tiled(self.cur, self.old, self.n, self.dt)                     # new state lands in the old buffer
+            e.step_fused_tiled(self.cur, self.old, self.n, self.dt, implicit_drag=self.implicit_drag)   # new state -> old buffer
         else:
             e.step_wrench_tiled(self.cur, self.n, self.dt, out=self.wrench, prev=self.old)
             e.integrate_tiled(self.cur, self.wrench, self.n, self.dt, state_out=self.old)   # overwrite the old buffer

@@ -71,3 +71,43 @@ def test_rtf_report(native_built):
     assert np.isfinite(ke).all() and ke[0] >= 0
     print("C2 closed loop:", r)
     sim.close()
+
+
+def test_implicit_drag_agrees_with_explicit_where_both_are_stable(native_built):
+    """Heavy buoys (damping * dt / m ~ 0.01): the linearly-implicit drag update is a first-order
+    perturbation of the explicit one."""
+    sc = scenes.scene_c2(n=512)
+    a, b = ClosedLoopSim(sc, implicit_drag=True), ClosedLoopSim(sc, implicit_drag=False)
+    a.run_eager(10); b.run_eager(10)
+    sa, sb = a.state(), b.state()
+    assert np.abs(sa[:, 0:3] - sb[:, 0:3]).max() < 1e-2            # after 10 steps: a small O(dt) difference (cm)
+    assert np.abs(sa[:, 7:10] - sb[:, 7:10]).max() < 1e-1
+    a.run_eager(110); b.run_eager(110)                             # 2 s: bobbing phases drift apart, both stay bounded
+    sa, sb = a.state(), b.state()
+    assert np.isfinite(sa).all() and np.isfinite(sb).all()
+    assert np.abs(sa[:, 7:10]).max() < 5.0 and np.abs(sb[:, 7:10]).max() < 5.0
+    a.close(); b.close()
+
+
+def test_config3_links_need_and_get_the_implicit_update(native_built):
+    """Config 3 bodies (0.45-18 kg links, damping 10-300 N s/m, 120 Hz): damping * dt / m reaches 5.5, the
+    explicit integrator diverges, the implicit one settles to terminal sinking speed."""
+    sc = scenes.scene_c3(envs=64)
+    sim = ClosedLoopSim(sc, implicit_drag=True)
+    sim.run(1200, graph_steps=100)
+    st = sim.state()
+    assert np.isfinite(st).all()
+    assert np.abs(st[:, 7:10]).max() < 2.0 and np.abs(st[:, 10:13]).max() < 5.0
+    assert np.abs(np.linalg.norm(st[:, 3:7], axis=1) - 1).max() < 1e-5
+    ke = sim.kinetic_energy()
+    assert np.isfinite(ke).all()
+    r = sim.measure_rtf(2400, graph_steps=100)
+    print("C3 (64 envs) closed loop, implicit drag:", r)
+    sim.close()
+    bad = ClosedLoopSim(sc, implicit_drag=False)
+    bad.run(1200, graph_steps=100)
+    sb = bad.state()
+    assert (not np.isfinite(sb).all()) or np.abs(sb[:, 7:10]).max() > 50.0      # explicit: blows up
+    bad.close()
+    with pytest.raises(ValueError):
+        ClosedLoopSim(sc, fused=False, implicit_drag=True)
