@@ -145,6 +145,15 @@ int hydro_step_components(hydro_t *h, int64_t n, const float *const state[HYDRO_
                           const float *const accel[HYDRO_PREV_FIELDS], float *const comps[HYDRO_COMP_FIELDS],
                           float *ratio, void *stream);
 
+/* The same on the calculators' own argument layout - calculate_hydrodynamic_forces(position,
+ * orientation_quat [x,y,z,w], linear_vel, angular_vel, linear_accel, angular_accel): (n,3) tensors
+ * ((n,4) for the quaternion; no alignment requirement) in, eight (n,3) tensors out in the order of the
+ * reference's return tuple.  One launch per call; the reference's Warp wrapper needs six assign
+ * copies plus a graph launch (warp_hydrodynamics_wrapper.py:85-120). */
+int hydro_step_components_aos(hydro_t *h, int64_t n, const float *position, const float *orientation_xyzw,
+                              const float *linear_vel, const float *angular_vel, const float *linear_accel,
+                              const float *angular_accel, float *const out[8], float *ratio, void *stream);
+
 /* Kinetic energy of the n bodies: out_dev[0] = sum 1/2 m |v|^2, out_dev[1] = sum 1/2 w^T I w (box
  * inertia; 0 unless `rotational`).  Two-stage deterministic fp64 reduction on device; the
  * result stays on the device so that the caller can all-reduce it over RCCL.  New

@@ -51,6 +51,7 @@ SIGNATURES = {
     "hydro_step_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float,
                                       c_void_p, c_void_p, c_void_p]),
     "hydro_step_components": (c_int, [c_void_p, c_int64, _FP, _FP, _FP, c_void_p, c_void_p]),
+    "hydro_step_components_aos": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [_FP, c_void_p, c_void_p]),
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
     "hydro_kinetic_energy_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),

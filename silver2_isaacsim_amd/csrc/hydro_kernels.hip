@@ -532,6 +532,60 @@ __global__ void __launch_bounds__(kBlock) components_kernel(const CompArgs a)
     if (a.ratio) a.ratio[i] = o.ratio;
 }
 
+// component mode on the calculator's own argument layout: six (n,3)/(n,4) tensors in, eight (n,3)
+// tensors out (+ ratio) - ONE launch per calculate_hydrodynamic_forces call, where the reference's
+// Warp wrapper needs six assign copies and a graph launch (warp_hydrodynamics_wrapper.py:85-120).
+struct CompAosArgs {
+    const float* pos; const float* quat_xyzw; const float* lin_vel; const float* ang_vel;
+    const float* lin_acc; const float* ang_acc;                 // (n,3) except quat (n,4)
+    const float* prm;                                            // engine-owned tiled parameter record
+    float* out[8];                                               // eight (n,3) tensors, reference order
+    float* ratio;
+    float rho, g;
+    uint32_t n;
+};
+
+template <bool HALF>
+__global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    hydro::BodyIn b;
+    b.px = a.pos[3 * i]; b.py = a.pos[3 * i + 1]; b.pz = a.pos[3 * i + 2];
+    // component-wise: a one-row slice handed over by a caller may start at any 4-byte offset
+    b.qx = a.quat_xyzw[4 * i]; b.qy = a.quat_xyzw[4 * i + 1]; b.qz = a.quat_xyzw[4 * i + 2]; b.qw = a.quat_xyzw[4 * i + 3];
+    b.vx = a.lin_vel[3 * i]; b.vy = a.lin_vel[3 * i + 1]; b.vz = a.lin_vel[3 * i + 2];
+    b.wx = a.ang_vel[3 * i]; b.wy = a.ang_vel[3 * i + 1]; b.wz = a.ang_vel[3 * i + 2];
+    b.ax = a.lin_acc[3 * i]; b.ay = a.lin_acc[3 * i + 1]; b.az = a.lin_acc[3 * i + 2];
+    b.bx = a.ang_acc[3 * i]; b.by = a.ang_acc[3 * i + 1]; b.bz = a.ang_acc[3 * i + 2];
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    float c[7];
+    if constexpr (HALF) {
+        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
+        b.dimx = *at<float>(a.prm, qo); b.dimy = *at<float>(a.prm, qo + 256u); b.dimz = *at<float>(a.prm, qo + 512u);
+        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(*at<unsigned short>(a.prm, ho + f * 128u));
+    } else {
+        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+        b.dimx = *at<float>(a.prm, qo); b.dimy = *at<float>(a.prm, qo + 256u); b.dimz = *at<float>(a.prm, qo + 512u);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = *at<float>(a.prm, qo + (3 + f) * 256u);
+    }
+    b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3]; b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
+    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g);
+    const float live = o.wet ? 1.0f : 0.0f;
+    const float v[8][3] = {{0.0f, 0.0f, o.buoy_z}, {o.drag_fx, o.drag_fy, o.drag_fz}, {o.lift_fx, o.lift_fy, o.lift_fz},
+                           {o.drag_tx, o.drag_ty, o.drag_tz}, {o.am_fx, o.am_fy, o.am_fz}, {o.am_tx, o.am_ty, o.am_tz},
+                           {live * (b.px + o.armb_x), live * (b.py + o.armb_y), live * (b.pz + o.armb_z)},
+                           {live * (b.px + o.armp_x), live * (b.py + o.armp_y), live * (b.pz + o.armp_z)}};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a.out[k][3 * i] = v[k][0]; a.out[k][3 * i + 1] = v[k][1]; a.out[k][3 * i + 2] = v[k][2];
+    }
+    if (a.ratio) a.ratio[i] = o.ratio;
+}
+
 // --------------------------------------------------------------------------
 // kinetic energy: wave64 shuffle -> LDS across the 4 waves -> one fp64 partial pair per
 // block -> fixed-order second stage (deterministic, no atomics).
@@ -1392,6 +1446,30 @@ static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, doub
     if (blocks > kKeBlocks) blocks = kKeBlocks;
     hipLaunchKernelGGL(ke_partial_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(ke_final_kernel, dim3(1), dim3(kBlock), 0, s, h->ke_partials, blocks, out_dev);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
+int hydro_step_components_aos(hydro_t* h, int64_t n, const float* position, const float* orientation_xyzw,
+                              const float* linear_vel, const float* angular_vel, const float* linear_accel,
+                              const float* angular_accel, float* const out[8], float* ratio, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!position || !orientation_xyzw || !linear_vel || !angular_vel || !linear_accel || !angular_accel || !out)
+        return fail(h, HYDRO_E_ARG, "null tensor pointer");
+    if (n > ((int64_t)1 << 26)) return fail(h, HYDRO_E_ARG, "at most 2^26 bodies per call");
+    if (n == 0) return HYDRO_OK;
+    CompAosArgs a;
+    a.pos = position; a.quat_xyzw = orientation_xyzw; a.lin_vel = linear_vel; a.ang_vel = angular_vel;
+    a.lin_acc = linear_accel; a.ang_acc = angular_accel; a.prm = h->params_tiled;
+    for (int k = 0; k < 8; ++k) { if (!out[k]) return fail(h, HYDRO_E_ARG, "null output tensor"); a.out[k] = out[k]; }
+    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.n = (uint32_t)n;
+    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(n, kBlock);
+    if (h->half_coeffs) hipLaunchKernelGGL(components_aos_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(components_aos_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }

@@ -270,6 +270,25 @@ class HydroEngine:
             self._table(out, nat.COMP_FIELDS), ratio.data_ptr(), self._stream(stream)))
         return out, ratio
 
+    def step_components_aos(self, position, orientation_xyzw, linear_vel, angular_vel, linear_accel, angular_accel,
+                            out: torch.Tensor, ratio: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+        """Component mode on the calculator's argument layout: (N,3)/(N,4) tensors in, out (8,N,3)."""
+        n = position.shape[0]
+        ins = (position, orientation_xyzw, linear_vel, angular_vel, linear_accel, angular_accel)
+        for t, w in zip(ins, (3, 4, 3, 3, 3, 3)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, w) or t.device != self.device:
+                raise ValueError(f"expected contiguous float32 ({n},{w}) tensor on {self.device}")
+        if out.shape != (8, n, 3) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"expected contiguous float32 (8,{n},3) output on {self.device}")
+        key = ("comp_aos", out.data_ptr(), n)
+        tab = self._tables.get(key)
+        if tab is None:
+            tab = self._tables[key] = nat.pointer_table([out.data_ptr() + k * n * 12 for k in range(8)])
+        self._check(self._lib.hydro_step_components_aos(
+            self._h, n, *[t.data_ptr() for t in ins], tab, ratio.data_ptr() if ratio is not None else None,
+            self._stream(stream)))
+        return out
+
     def kinetic_energy(self, state: torch.Tensor, rotational: bool = False, out: torch.Tensor | None = None,
                        stream=None) -> torch.Tensor:
         """[sum 1/2 m v^2, sum 1/2 w.I.w] as a float64 device tensor of shape (2,)."""

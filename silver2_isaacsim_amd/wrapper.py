@@ -73,9 +73,6 @@ class HipHydrodynamicsWrapper:
         self._engine = HydroEngine(n, self.device, self.water_density, self.gravity)
         self._engine.set_params(params.astype(np.float32), coeff_dtype)
         dev = self._engine.device
-        self._state = torch.empty((13, n), dtype=torch.float32, device=dev)
-        self._accel = torch.empty((6, n), dtype=torch.float32, device=dev)
-        self._comps = torch.empty((24, n), dtype=torch.float32, device=dev)
         self._comps_aos = torch.empty((8, n, 3), dtype=torch.float32, device=dev)
         self._ratio = torch.empty((n,), dtype=torch.float32, device=dev)
         self._force = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -99,14 +96,10 @@ class HipHydrodynamicsWrapper:
         """(buoyancy_force, drag_force, lift_force, drag_torque, added_mass_force,
         added_mass_torque, center_of_buoyancy, center_of_pressure), each (N,3) float32.
         `orientation_quat` is [x, y, z, w] as for both reference calculators."""
-        p, q = self._rows(position, 3), self._rows(orientation_quat, 4)
-        v, w = self._rows(linear_vel, 3), self._rows(angular_vel, 3)
-        a, al = self._rows(linear_accel, 3), self._rows(angular_accel, 3)
-        st = self._state
-        st[0:3].copy_(p.t()); st[3:7].copy_(q.t()); st[7:10].copy_(v.t()); st[10:13].copy_(w.t())
-        self._accel[0:3].copy_(a.t()); self._accel[3:6].copy_(al.t())
-        self._engine.step_components(st, self._accel, out=self._comps, ratio=self._ratio)
-        self._comps_aos.copy_(self._comps.view(8, 3, self.n).transpose(1, 2))
+        ins = [self._rows(x, w).contiguous() for x, w in ((position, 3), (orientation_quat, 4), (linear_vel, 3),
+                                                           (angular_vel, 3), (linear_accel, 3), (angular_accel, 3))]
+        # one kernel launch: (N,3)/(N,4) tensors in, the eight (N,3) outputs straight into wrapper-owned memory
+        self._engine.step_components_aos(*ins, out=self._comps_aos, ratio=self._ratio)
         return tuple(self._comps_aos[k] for k in range(8))
 
     def calculate_wrench(self, position, orientation_quat, linear_vel, angular_vel, delta_time: float):

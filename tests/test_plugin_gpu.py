@@ -190,3 +190,41 @@ def test_headless_buoy_demo(tmp_path, native_built):
     assert out["stats"]["physics_steps"] == 900 and out["stats"]["rtf"] > 1.0
     rows = list(csv.reader(open(out["csv"])))
     assert len(rows) == 901 and rows[0][1] == "z_position" and float(rows[-1][1]) == pytest.approx(z[-1], abs=1e-5)
+
+
+def test_calculator_is_one_launch_and_matches_the_soa_component_entry(native_built):
+    """calculate_hydrodynamic_forces goes through hydro_step_components_aos: same bits as the plain-SoA
+    component entry, on ragged sizes; and a per-call latency figure for the per-prim flow (N = 1)."""
+    import time
+    from silver2_isaacsim_amd import scenes
+    from silver2_isaacsim_amd.engine import HydroEngine
+    fx = load_golden("c4")
+    n = 777
+    p = fx["params"][:n]
+    w = HipHydrodynamicsWrapper(p[:, 0], p[:, 1], p[:, 2], p[:, 3], p[:, 4], p[:, 5], p[:, 6], 1025.0, 9.81,
+                                p[:, 8], p[:, 9], p[:, 7], device="cuda:0")
+    st = torch.from_numpy(fx["state"][:n]).cuda()
+    acc = ((fx["state"][:n, 7:13].astype(np.float64) - fx["prev"][:n].astype(np.float64)) / float(fx["dt"])).astype(np.float32)
+    a = torch.from_numpy(acc).cuda()
+    out = w.calculate_hydrodynamic_forces(st[:, 0:3], st[:, 3:7], st[:, 7:10], st[:, 10:13], a[:, 0:3], a[:, 3:6])
+    eng = HydroEngine(n, "cuda:0"); eng.set_params(p)
+    comps, ratio = eng.step_components(torch.from_numpy(scenes.to_soa(fx["state"][:n])).cuda(), torch.from_numpy(scenes.to_soa(acc)).cuda())
+    torch.cuda.synchronize()
+    ref = comps.cpu().numpy().T.reshape(n, 8, 3)
+    for k in range(8):
+        assert np.array_equal(out[k].cpu().numpy(), ref[:, k, :]), k
+    assert np.array_equal(w.sub_ratio.cpu().numpy(), ratio.cpu().numpy())
+    eng.close(); w.close()
+    # the reference's per-prim flow: one body per call
+    w1 = HipHydrodynamicsWrapper(1, 1, 1, 1.2, 0.8, 300, 150, 1025.0, 9.81, 0.05, 0.02, 1.0, device="cuda:0")
+    args = [st[:1, 0:3].contiguous(), st[:1, 3:7].contiguous(), st[:1, 7:10].contiguous(), st[:1, 10:13].contiguous(),
+            a[:1, 0:3].contiguous(), a[:1, 3:6].contiguous()]
+    for _ in range(50):
+        w1.calculate_hydrodynamic_forces(*args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        w1.calculate_hydrodynamic_forces(*args)
+    torch.cuda.synchronize()
+    print(f"calculate_hydrodynamic_forces, N=1: {(time.perf_counter() - t0) / 2000 * 1e6:.1f} us per call")
+    w1.close()
