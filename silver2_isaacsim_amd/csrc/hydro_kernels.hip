@@ -408,55 +408,69 @@ struct AosArgs {
     int64_t n;
 };
 
+// Wave-private staging: each wavefront transposes ITS 64 bodies through its own LDS slice (positions
+// 768 B, velocities 1536 B in; forces + torques 1536 B out), so no workgroup barrier is needed at all.
+// LDS operations of one wave execute in order; what has to be prevented is the COMPILER moving a lane's
+// reads above other lanes' writes (per thread the addresses differ), hence the wavefront-scope fences.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool HALF, bool NT>
 __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[kBlock * 6];     // 6 KiB: velocities, then F|T
-    __shared__ __attribute__((aligned(16))) float lds_pos[kBlock * 3]; // 3 KiB
-
-    const int t = threadIdx.x;
-    const int64_t block0 = (int64_t)blockIdx.x * kBlock;
-    const int64_t i = block0 + t;
-    const int64_t left = a.n - block0;                      // bodies in this block (>=1)
-    const bool whole = left >= kBlock;
-
+    constexpr int kWaves = kBlock / 64;
+    __shared__ __attribute__((aligned(16))) float lds_all[kWaves][64 * 9];   // per wave: 6*64 vel | 3*64 pos  (2.25 KiB)
     using f4 = float __attribute__((ext_vector_type(4)));
-    if (whole) {
-        const f4* p4 = reinterpret_cast<const f4*>(a.pos + block0 * 3);
-        const f4* v4 = reinterpret_cast<const f4*>(a.vel + block0 * 6);
-        if (t < kBlock * 3 / 4) reinterpret_cast<f4*>(lds_pos)[t] = ldg<NT>(p4 + t);
-        reinterpret_cast<f4*>(lds)[t] = ldg<NT>(v4 + t);
-        if (t < kBlock * 6 / 4 - kBlock) reinterpret_cast<f4*>(lds)[t + kBlock] = ldg<NT>(v4 + t + kBlock);
-    } else {
-        for (int64_t k = t; k < left * 3; k += kBlock) lds_pos[k] = a.pos[block0 * 3 + k];
-        for (int64_t k = t; k < left * 6; k += kBlock) lds[k] = a.vel[block0 * 6 + k];
-    }
-    __syncthreads();
 
-    const bool live = i < a.n;
-    const int64_t ic = live ? i : a.n - 1;                  // clamp: idle lanes redo the last body
-    const int tc = (int)(ic - block0);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float* lds = lds_all[wave];                    // [0,384): velocities then F|T   [384,576): positions
+    float* lds_pos = lds + 384;
+    const uint32_t n = (uint32_t)a.n;
+    const uint32_t w0 = (blockIdx.x * kWaves + wave) * 64u;        // first body of this wave
+    if (w0 >= n) return;                                           // whole wave idle (no workgroup barriers below)
+    const uint32_t left = n - w0;
+    const bool whole = left >= 64u;
+
+    if (whole) {
+        const f4* p4 = reinterpret_cast<const f4*>(a.pos + (size_t)w0 * 3);
+        const f4* v4 = reinterpret_cast<const f4*>(a.vel + (size_t)w0 * 6);
+        if (lane < 48u) reinterpret_cast<f4*>(lds_pos)[lane] = ldg<NT>(p4 + lane);
+        reinterpret_cast<f4*>(lds)[lane] = ldg<NT>(v4 + lane);
+        if (lane < 32u) reinterpret_cast<f4*>(lds)[lane + 64] = ldg<NT>(v4 + lane + 64);
+    } else {
+        for (uint32_t k = lane; k < left * 3; k += 64u) lds_pos[k] = a.pos[(size_t)w0 * 3 + k];
+        for (uint32_t k = lane; k < left * 6; k += 64u) lds[k] = a.vel[(size_t)w0 * 6 + k];
+    }
+    wave_lds_fence();
+
+    const bool live = lane < left;
+    const uint32_t lc = live ? lane : left - 1;                    // idle lanes of the last wave redo its last body
+    const uint32_t ic = w0 + lc;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-    s[0] = lds_pos[3 * tc]; s[1] = lds_pos[3 * tc + 1]; s[2] = lds_pos[3 * tc + 2];
+    s[0] = lds_pos[3 * lc]; s[1] = lds_pos[3 * lc + 1]; s[2] = lds_pos[3 * lc + 2];
     const f4 q = ldg<NT>(reinterpret_cast<const f4*>(a.quat) + ic);
     if (a.quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
     else             { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
 #pragma unroll
-    for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * tc + f];
-    const uint32_t tile = (uint32_t)ic >> 6, lane = (uint32_t)ic & 63u;
-    const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + lane) * 4u;
+    for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * lc + f];
+    const uint32_t tile = ic >> 6, tl = ic & 63u;                  // w0 is a multiple of 64: tile == this wave's tile
+    const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + tl) * 4u;
 #pragma unroll
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
     if constexpr (HALF) {
-        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
+        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + tl * 4u;
 #pragma unroll
         for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
         mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
-        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
+        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + tl * 2u;
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
     } else {
-        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + tl * 4u;
 #pragma unroll
         for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
 #pragma unroll
@@ -470,19 +484,19 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
 #pragma unroll
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv, po + f * 256u), s[7 + f]);
     }
-    __syncthreads();                                        // everyone has read its velocity
-    lds[3 * t] = w.fx; lds[3 * t + 1] = w.fy; lds[3 * t + 2] = w.fz;
-    lds[kBlock * 3 + 3 * t] = w.tx; lds[kBlock * 3 + 3 * t + 1] = w.ty; lds[kBlock * 3 + 3 * t + 2] = w.tz;
-    __syncthreads();
+    wave_lds_fence();                                              // every lane has read its velocity
+    lds[3 * lane] = w.fx; lds[3 * lane + 1] = w.fy; lds[3 * lane + 2] = w.fz;
+    lds[192 + 3 * lane] = w.tx; lds[192 + 3 * lane + 1] = w.ty; lds[192 + 3 * lane + 2] = w.tz;
+    wave_lds_fence();
     if (whole) {
-        if (t < kBlock * 3 / 4) {
-            stg<NT>(reinterpret_cast<f4*>(a.force + block0 * 3) + t, reinterpret_cast<const f4*>(lds)[t]);
-            stg<NT>(reinterpret_cast<f4*>(a.torque + block0 * 3) + t, reinterpret_cast<const f4*>(lds + kBlock * 3)[t]);
+        if (lane < 48u) {
+            stg<NT>(reinterpret_cast<f4*>(a.force + (size_t)w0 * 3) + lane, reinterpret_cast<const f4*>(lds)[lane]);
+            stg<NT>(reinterpret_cast<f4*>(a.torque + (size_t)w0 * 3) + lane, reinterpret_cast<const f4*>(lds + 192)[lane]);
         }
     } else {
-        for (int64_t k = t; k < left * 3; k += kBlock) {
-            a.force[block0 * 3 + k] = lds[k];
-            a.torque[block0 * 3 + k] = lds[kBlock * 3 + k];
+        for (uint32_t k = lane; k < left * 3; k += 64u) {
+            a.force[(size_t)w0 * 3 + k] = lds[k];
+            a.torque[(size_t)w0 * 3 + k] = lds[192 + k];
         }
     }
 }
