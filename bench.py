@@ -53,6 +53,12 @@ WORKLOADS = {
 }
 
 
+# which entry of BASELINE.json "configs" a workload is (C5 = configs[4] is the one whose line asks for
+# "achieved HBM GB/s vs peak", i.e. the roofline part of the metric; configs[1..3] are launch-bound
+# parity cases and are reported in `extras`)
+BASELINE_CONFIG = {"c2": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}
+
+
 def build_scene(kind: str, n: int, seed: int):
     if kind == "c2":
         return scenes.scene_c2(n=n, seed=seed)
@@ -386,7 +392,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "bodies_per_gpu": sc.n, "coefficients": coeff,
+            "config": {"workload": desc, "baseline_config": BASELINE_CONFIG.get(args.workload, "variant"),
+                       "bodies_per_gpu": sc.n, "coefficients": coeff,
                        "scene_replicas_per_gpu": args.scenes, "bytes_per_body_step": bpb,
                        "sharding": f"bodies x{world} (no data-path collective)",
                        "layout": "tiled SoA [tile][field][64]" if args.layout == "tiled" else "plain SoA",
