@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""DEV-ONLY: interleaved A/B of libhydro.so built with different -D flags (prebuilt here, see BUILD below;
+the variants travel to the GPU box under scripts/_variants/).  Times the C5 headline step (tiled, fp16 coeffs,
+4 rotating replicas) and the fp32 4M step.
+  build (CPU container):  python scripts/ab_variants.py build name1=-DFOO=1 name2=-DFOO=2 ...
+  run   (GPU box):        python scripts/ab_variants.py run name1 name2 ...        -> gpurun_out/ab.log"""
+import os, statistics, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "gpurun_out"); os.makedirs(OUT, exist_ok=True)
+
+
+VARDIR = os.path.join(REPO, "scripts", "_variants"); os.makedirs(VARDIR, exist_ok=True)   # *.so is git-ignored, not gpurun-ignored
+
+
+def so(name):
+    return os.path.join(VARDIR, f"libvar_{name}.so")
+
+
+if sys.argv[1] == "build":
+    from silver2_isaacsim_amd import build as hb
+    import shutil
+    for spec in sys.argv[2:]:
+        name, _, flags = spec.partition("=")
+        hb.build(force=True, extra_flags=[f for f in flags.split(",") if f])
+        shutil.copy(hb.OUT, so(name)); print("built", so(name), flags)
+    hb.build(force=True)                      # leave the product library as the plain build
+    sys.exit(0)
+
+import numpy as np, torch
+from silver2_isaacsim_amd import _native as nat, scenes
+from silver2_isaacsim_amd.engine import HydroEngine
+import bench
+names = sys.argv[2:]
+dev = torch.device("cuda:0"); stream = torch.cuda.Stream(dev)
+LOG = open(os.path.join(OUT, "ab.log"), "a")
+def say(*a):
+    s = " ".join(str(x) for x in a); print(s, flush=True); LOG.write(s + "\n"); LOG.flush()
+
+for kind, n, coeff, sets in (("c5", 1048576, "f16", 4), ("c5", 1048576, "f32", 4), ("c5", 4194304, "f32", 2)):
+    sc = bench.build_scene(kind, n, 11)
+    reps = {}
+    for nm in names:
+        nat._lib = nat.load(so(nm))           # HydroEngine binds whatever nat.load() returns
+        reps[nm] = [bench.Replica(sc, coeff, dev, roll=7919 * k) for k in range(sets)]
+    outs = {nm: reps[nm][0] for nm in names}
+    with torch.cuda.stream(stream):
+        for nm in names: reps[nm][0].step()
+    stream.synchronize()
+    ref = reps[names[0]][0].out
+    for nm in names[1:]:
+        d = (reps[nm][0].out - ref).abs().max().item()
+        say(f"{kind} n={n} {coeff}: max |{nm} - {names[0]}| = {d:.3e}")
+    bench.spin_up(reps[names[0]], stream, 1.0)
+    K, ROUNDS = 400 if n <= 2 ** 20 else 120, 9
+    res = {nm: [] for nm in names}
+    with torch.cuda.stream(stream):
+        for r in range(ROUNDS):
+            for nm in names:
+                R = reps[nm]
+                for k in range(40): R[k % sets].step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for k in range(K): R[k % sets].step()
+                e1.record(stream); stream.synchronize()
+                res[nm].append(e0.elapsed_time(e1) * 1e3 / K)
+    for nm in names:
+        v = res[nm]
+        say(f"{kind} n={n} {coeff} {nm:12s}: median {statistics.median(v):7.2f} us  min {min(v):7.2f}  max {max(v):7.2f}")
+    for nm in names:
+        for R in reps[nm]: R.engine.close()
+    del reps
+    torch.cuda.empty_cache()

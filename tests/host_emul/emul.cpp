@@ -24,3 +24,23 @@ extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, con
     }
     return 0;
 }
+
+// BodyOut of one body as 27 floats (numerics diagnostics, scripts/diag_tail.py):
+// ratio buoy_z drag_f[3] lift_f[3] drag_t[3] am_f[3] am_t[3] armb[3] armp[3] dragarm_t[3] lin_k ang_k
+extern "C" int emul_body(const float* s, const float* pv, const float* pr, float rho, float g, float inv_dt, float* out)
+{
+    hydro::BodyIn b;
+    b.px = s[0]; b.py = s[1]; b.pz = s[2]; b.qx = s[3]; b.qy = s[4]; b.qz = s[5]; b.qw = s[6];
+    b.vx = s[7]; b.vy = s[8]; b.vz = s[9]; b.wx = s[10]; b.wy = s[11]; b.wz = s[12];
+    b.ax = (b.vx - pv[0]) * inv_dt; b.ay = (b.vy - pv[1]) * inv_dt; b.az = (b.vz - pv[2]) * inv_dt;
+    b.bx = (b.wx - pv[3]) * inv_dt; b.by = (b.wy - pv[4]) * inv_dt; b.bz = (b.wz - pv[5]) * inv_dt;
+    b.dimx = pr[0]; b.dimy = pr[1]; b.dimz = pr[2]; b.cd_lin = pr[3]; b.cd_ang = pr[4];
+    b.damp_lin = pr[5]; b.damp_ang = pr[6]; b.lift = pr[7]; b.am_lin = pr[8]; b.am_ang = pr[9];
+    const hydro::BodyOut o = hydro::solve_body(b, rho, g);
+    const float v[27] = {o.ratio, o.buoy_z, o.drag_fx, o.drag_fy, o.drag_fz, o.lift_fx, o.lift_fy, o.lift_fz,
+                         o.drag_tx, o.drag_ty, o.drag_tz, o.am_fx, o.am_fy, o.am_fz, o.am_tx, o.am_ty, o.am_tz,
+                         o.armb_x, o.armb_y, o.armb_z, o.armp_x, o.armp_y, o.armp_z,
+                         o.dragarm_tx, o.dragarm_ty, o.dragarm_tz, o.lin_k};
+    for (int i = 0; i < 27; ++i) out[i] = v[i];
+    return 0;
+}
