@@ -25,7 +25,7 @@ extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, con
     return 0;
 }
 
-// BodyOut of one body as 27 floats (numerics diagnostics, scripts/diag_tail.py):
+// BodyOut of one body as 27 floats (numerics diagnostics, tests/tools/diag_tail.py):
 // ratio buoy_z drag_f[3] lift_f[3] drag_t[3] am_f[3] am_t[3] armb[3] armp[3] dragarm_t[3] lin_k ang_k
 extern "C" int emul_body(const float* s, const float* pv, const float* pr, float rho, float g, float inv_dt, float* out)
 {

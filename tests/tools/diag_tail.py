@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """CPU-only numerics study of the error tail: csrc/hydro_body.h compiled for the host (tests/host_emul)
 against the fp64 C oracle over many seeded scenes; prints the worst bodies with their force budget.
-python scripts/diag_tail.py [seeds] [n] [threshold]"""
+python tests/tools/diag_tail.py [seeds] [n] [threshold]"""
 import ctypes, os, sys
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
 from oracle import c_oracle, hydro_oracle as ho
 from silver2_isaacsim_amd import scenes
 

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Parity soak: many seeded scenes through every fused entry point, EVERY body compared with the fp64 C
-oracle (OpenMP).  Writes profiles/r01_parity_soak.json.   python scripts/soak_parity.py [seeds] [n]"""
+oracle (OpenMP).  Writes profiles/r01_parity_soak.json.   python tests/tools/soak_parity.py [seeds] [n]"""
 import json, os, sys, time
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
 from oracle import c_oracle, hydro_oracle as ho
 from silver2_isaacsim_amd import scenes
 from silver2_isaacsim_amd.engine import HydroEngine
