@@ -46,7 +46,7 @@ int main(int argc, char **argv)
     /* error model first: status codes, never a crash */
     if (hydro_create(0, -1, &h) != HYDRO_E_ARG || hydro_create(999, 16, &h) != HYDRO_E_DEVICE) { fprintf(stderr, "error model broken\n"); return 4; }
     CHECK_HYDRO(h, hydro_create(0, n, &h));
-    CHECK_HYDRO(h, hydro_set_scene(h, 1025.0f, 9.81f));
+    CHECK_HYDRO(h, hydro_set_scene(h, 1025.0, 9.81));
 
     /* device buffers: plain SoA, one run of n floats per field */
     float *s_soa = to_soa(state, n, 13), *p_soa = to_soa(prev, n, 6), *q_soa = to_soa(params, n, 11);

@@ -68,8 +68,10 @@ const char *hydro_last_error(const hydro_t *h);
 int64_t     hydro_capacity(const hydro_t *h);
 
 /* Scene scalars: water density and gravity ("globals", hydrodynamics_config.json:2-5;
- * ctor arguments water_density / gravity, numba_hydrodynamics_wrapper.py:9-10). */
-int hydro_set_scene(hydro_t *h, float water_density, float gravity);
+ * ctor arguments water_density / gravity, numba_hydrodynamics_wrapper.py:9-10).  Doubles, as the
+ * reference passes Python floats: 9.81 is not an fp32 number, and the buoyancy and drag terms that
+ * cancel along z are evaluated in fp64 inside the kernels. */
+int hydro_set_scene(hydro_t *h, double water_density, double gravity);
 
 /* Per-body constants: the remaining ten ctor arguments of the reference wrappers
  * (numba_hydrodynamics_wrapper.py:9-32) plus the rigid-body mass used by the clamp

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhydro.so")
@@ -31,7 +31,7 @@ SIGNATURES = {
     "hydro_destroy": (c_int, [c_void_p]),
     "hydro_last_error": (c_char_p, [c_void_p]),
     "hydro_capacity": (c_int64, [c_void_p]),
-    "hydro_set_scene": (c_int, [c_void_p, c_float, c_float]),
+    "hydro_set_scene": (c_int, [c_void_p, c_double, c_double]),
     "hydro_set_params_f32": (c_int, [c_void_p, c_int64, _FP, c_int]),
     "hydro_set_params_f16": (c_int, [c_void_p, c_int64, _FP, c_int]),
     "hydro_reset_prev_velocity": (c_int, [c_void_p]),

@@ -112,13 +112,18 @@ struct BodyOut {
     float armb_x, armb_y, armb_z;   // cob - p   (0 when dry)
     float armp_x, armp_y, armp_z;   // cop - p   (0 when dry)
     float dragarm_tx, dragarm_ty, dragarm_tz;   // (cop - p) x drag_force, cancellation-free form
+    float tbx, tby;                 // buoyancy torque (cob - p) x (0,0,B), evaluated in fp64 (0 when dry)
+    float fz_core;                  // buoyancy + drag force along z, summed in fp64 (0 when dry)
     float lin_k, ang_k;             // drag_force = lin_k * v, drag_torque = ang_k * w   (both <= 0; 0 when dry)
     bool wet;
 };
 
 // A1-A11.  rho, g are scene scalars (hydrodynamics_config.json:2-5 "globals").
-HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
+// They arrive as doubles (the reference passes Python floats, numba_hydrodynamics_wrapper.py:9-10): 9.81 is
+// not an fp32 number, and rounding it costs 4e-8 of the buoyancy before any arithmetic has happened.
+HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64)
 {
+    const float rho = (float)rho64, g = (float)g64;
     BodyOut o;
 
     // ---- A1: rotation matrix, fp32 (numba_hydrodynamics.py:14-49) ----
@@ -161,6 +166,17 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     if (dry_by_extent) ratio = 0.0f;
     const bool wet = ratio > kDryEps;
     o.wet = wet;
+    // ---- A5 in fp64: buoyancy (:282) from an fp64 ratio (one Newton step on -z_lo / height) ----
+    // Buoyancy is routinely the largest term of the wrench, and two other terms routinely cancel it: drag
+    // along z (a body sinking or rising near its terminal velocity; 180x cancellation observed) and the
+    // drag torques against its lever-arm torque.  The fp32 roundings of the partners (1e-7 each, 4e-8 from
+    // rounding g = 9.81 alone) are amplified by the cancellation ratio, so buoyancy, the z-drag and the
+    // buoyancy torque are evaluated in fp64 from the raw inputs and rounded AFTER they have been summed
+    // (below: fz_core, tbx, tby).  ~60 fp64 operations per body, hidden behind HBM on MI355X.
+    const double vol64 = ((double)b.dimx * (double)b.dimy) * (double)b.dimz;
+    double ratio64 = (double)ratio + ((-zlo) - (double)ratio * (extent + extent)) * (double)fast_rcp(height);
+    if (ratio >= 1.0f) ratio64 = 1.0;                   // clamped, degenerate height or fully in
+    const double buoy64 = (rho64 * g64) * (ratio64 * vol64);
 
     // ---- A3: centre of buoyancy from integer lattice sums (:69-84,99-103) ----
     // z_ijk < 0 for lattice index (i,j,k); S_a = sum of index a over the wet points.  The test is the
@@ -191,6 +207,19 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     float armb_x = r00 * lbx + r01 * lby + r02 * lbz;
     float armb_y = r10 * lbx + r11 * lby + r12 * lbz;
     float armb_z = r20 * lbx + r21 * lby + r22 * lbz;
+    // buoyancy torque (cob - p) x (0,0,B) = (arm_y B, -arm_x B, 0): the HORIZONTAL lever arm times the largest
+    // force.  For a near-upright body arm_x, arm_y are small components of the rotated lattice mean
+    // (|arm| ~ h_z): the fp32 product R l only delivers them to ~1e-7 |arm| absolute (4e-6 relative
+    // observed).  Rotate in fp64 instead:  R l = l + 2 (w t + q x t),  t = q x l  (x, y components only).
+    float tbx, tby;
+    {
+        const double l0 = lbx, l1 = lby, l2 = lbz;
+        const double bt0 = dqy * l2 - dqz * l1, bt1 = dqz * l0 - dqx * l2, bt2 = dqx * l1 - dqy * l0;
+        const double arm64x = l0 + 2.0 * (dqw * bt0 + (dqy * bt2 - dqz * bt1));
+        const double arm64y = l1 + 2.0 * (dqw * bt1 + (dqz * bt0 - dqx * bt2));
+        tbx = (float)(arm64y * buoy64);
+        tby = (float)(-arm64x * buoy64);
+    }
 
     // ---- A5: buoyancy (:282) ----
     const float volume = b.dimx * b.dimy * b.dimz;
@@ -215,16 +244,32 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     const double gx_ = (dqy * tz_ - dqz * ty_) - dqw * tx_;
     const double gy_ = (dqz * tx_ - dqx * tz_) - dqw * ty_;
     const double gz_ = (dqx * ty_ - dqy * tx_) - dqw * tz_;
-    const float ux = (float)(dvx + 2.0 * gx_) * inv_speed;
-    const float uy = (float)(dvy + 2.0 * gy_) * inv_speed;
-    const float uz = (float)(dvz + 2.0 * gz_) * inv_speed;
+    const double urx = dvx + 2.0 * gx_, ury = dvy + 2.0 * gy_, urz = dvz + 2.0 * gz_;      // R^T v
+    const float ux = (float)urx * inv_speed;
+    const float uy = (float)ury * inv_speed;
+    const float uz = (float)urz * inv_speed;
     const float sx = (ux < 0.0f) ? 1.0f : -1.0f;        // sign of the face opposing the flow
     const float sy = (uy < 0.0f) ? 1.0f : -1.0f;
     const float sz = (uz < 0.0f) ? 1.0f : -1.0f;
     const float fax = ((ux != 0.0f) && (b.pz + sx * ex < 0.0f)) ? fabsf(ux) * (b.dimy * b.dimz) : 0.0f;
     const float fay = ((uy != 0.0f) && (b.pz + sy * ey < 0.0f)) ? fabsf(uy) * (b.dimx * b.dimz) : 0.0f;
     const float faz = ((uz != 0.0f) && (b.pz + sz * ez < 0.0f)) ? fabsf(uz) * (b.dimx * b.dimy) : 0.0f;
+    const bool cx_ = fax != 0.0f, cy_ = fay != 0.0f, cz_ = faz != 0.0f;
     const float area = fax + fay + faz;                 // 0 at rest (u = 0): N1 completion
+    // buoyancy + drag along z in fp64, rounded after the sum.  s A needs no division:
+    // s A = sum_a |(R^T v)_a| area_a with the un-normalised fp64 R^T v; |v| by one Newton step on sqrt.
+    float fz_core;
+    {
+        const double ddz = b.dimz, fxy = (double)b.dimx * (double)b.dimy;
+        const double sA64 = (cx_ ? fabs(urx) * ((double)b.dimy * ddz) : 0.0) + (cy_ ? fabs(ury) * ((double)b.dimx * ddz) : 0.0)
+                          + (cz_ ? fabs(urz) * fxy : 0.0);
+        const double v2_64 = dvx * dvx + dvy * dvy + dvz * dvz;
+        const double speed64 = (double)speed + (v2_64 - (double)speed * (double)speed) * (0.5 * (double)inv_speed);
+        const double quad64 = moving ? (0.5 * rho64) * ((double)b.cd_lin * sA64) : 0.0;
+        const double scale64 = (speed < kLowSpeed) ? speed64 * 5.0 : 1.0;
+        const double link64 = (quad64 + (double)b.damp_lin * scale64) * ratio64;
+        fz_core = (float)(buoy64 - link64 * dvz);
+    }
     const bool has_area = area > kAreaEps;
     const float inv_area = has_area ? fast_rcp(area) : 0.0f;
     const float lpx = sx * hx * fax * inv_area, lpy = sy * hy * fay * inv_area, lpz = sz * hz * faz * inv_area;
@@ -327,6 +372,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, float rho, float g)
     o.am_tx = HYDRO_LIVE(r00 * tlx + r01 * tly + r02 * tlz);
     o.am_ty = HYDRO_LIVE(r10 * tlx + r11 * tly + r12 * tlz);
     o.am_tz = HYDRO_LIVE(r20 * tlx + r21 * tly + r22 * tlz);
+    o.fz_core = HYDRO_LIVE(fz_core); o.tbx = HYDRO_LIVE(tbx); o.tby = HYDRO_LIVE(tby);
     o.lin_k = HYDRO_LIVE(lin_k); o.ang_k = HYDRO_LIVE(ang_k);
     o.armb_x = HYDRO_LIVE(armb_x); o.armb_y = HYDRO_LIVE(armb_y); o.armb_z = HYDRO_LIVE(armb_z);
     o.armp_x = HYDRO_LIVE(armp_x); o.armp_y = HYDRO_LIVE(armp_y); o.armp_z = HYDRO_LIVE(armp_z);
@@ -343,10 +389,10 @@ HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass)
 {
     const float fx = (o.drag_fx + o.lift_fx) + o.am_fx;
     const float fy = (o.drag_fy + o.lift_fy) + o.am_fy;
-    const float fz = (o.buoy_z + (o.drag_fz + o.lift_fz)) + o.am_fz;
+    const float fz = o.fz_core + (o.lift_fz + o.am_fz);            // fz_core = buoyancy + drag_z, summed in fp64
     // tau = arm_b x (0,0,Fb) + arm_p x F_drag + arm_p x F_lift + tau_drag + tau_am
-    const float tx = o.armb_y * o.buoy_z + o.dragarm_tx + (o.armp_y * o.lift_fz - o.armp_z * o.lift_fy) + o.drag_tx + o.am_tx;
-    const float ty = -o.armb_x * o.buoy_z + o.dragarm_ty + (o.armp_z * o.lift_fx - o.armp_x * o.lift_fz) + o.drag_ty + o.am_ty;
+    const float tx = o.tbx + (o.dragarm_tx + (o.armp_y * o.lift_fz - o.armp_z * o.lift_fy) + o.drag_tx + o.am_tx);
+    const float ty = o.tby + (o.dragarm_ty + (o.armp_z * o.lift_fx - o.armp_x * o.lift_fz) + o.drag_ty + o.am_ty);
     const float tz = o.dragarm_tz + (o.armp_x * o.lift_fy - o.armp_y * o.lift_fx) + o.drag_tz + o.am_tz;
     const float f_mag = fast_sqrt(fx * fx + fy * fy + fz * fz);
     const float scale = fminf(1.0f, mass * kMaxAccel * fast_rcp(f_mag + kClampEps));

@@ -126,14 +126,15 @@ struct SoaArgs {
     const void* coef[7];                     // float or __half
     const float* mass;
     float* out[HYDRO_WRENCH_FIELDS];
-    float rho, g, inv_dt;
+    double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
+    float inv_dt;
     int64_t n;
 };
 
 // One body from already-loaded scalars.
 __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
                                                      const float (&d)[3], const float (&c)[7], float mass,
-                                                     float rho, float g, float inv_dt)
+                                                     double rho, double g, float inv_dt)
 {
     hydro::BodyIn b;
     b.px = s[0]; b.py = s[1]; b.pz = s[2];
@@ -153,7 +154,7 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
 // Same, also handing back the (clamped) linear / angular drag coefficients for the implicit integrator.
 __device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
                                                        const float (&d)[3], const float (&c)[7], float mass,
-                                                       float rho, float g, float inv_dt, float& k_lin, float& k_ang)
+                                                       double rho, double g, float inv_dt, float& k_lin, float& k_ang)
 {
     hydro::BodyIn b;
     b.px = s[0]; b.py = s[1]; b.pz = s[2];
@@ -242,7 +243,8 @@ struct TiledArgs {
     float* pv_out;    uint32_t pvo_stride;     // WRITE_PREV only
     const float* prm;                          // engine-owned: [tiles][11][64] f32, or f16 record (below)
     float* out;       uint32_t out_stride;     // 6 fields
-    float rho, g, inv_dt;
+    double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
+    float inv_dt;
     uint32_t n;
 };
 // fp16-coefficient parameter record per tile: [dimx dimy dimz mass][64] f32 (1024 B) then
@@ -404,7 +406,8 @@ struct AosArgs {
     float* torque;          // (n,3)
     float* pv;              // engine-owned previous velocity, tiled [tiles][6][64] (read, then updated)
     const float* prm;       // engine-owned parameters, tiled record (f32 or fp16-coefficient form)
-    float rho, g, inv_dt;
+    double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
+    float inv_dt;
     int64_t n;
 };
 
@@ -511,7 +514,7 @@ struct CompArgs {
     const void* coef[7];
     float* out[HYDRO_COMP_FIELDS];
     float* ratio;
-    float rho, g;
+    double rho, g;
     int64_t n;
 };
 
@@ -555,7 +558,7 @@ struct CompAosArgs {
     const float* prm;                                            // engine-owned tiled parameter record
     float* out[8];                                               // eight (n,3) tensors, reference order
     float* ratio;
-    float rho, g;
+    double rho, g;
     uint32_t n;
 };
 
@@ -848,7 +851,7 @@ struct hydro_engine {
     int64_t capacity = 0;
     int64_t stride = 0;            // padded field stride of the engine-owned SoA buffers (floats)
     int64_t n_params = 0;          // bodies for which parameters have been set
-    float rho = 1025.0f, g = 9.81f;
+    double rho = 1025.0, g = 9.81;
     bool half_coeffs = false;
     float* params = nullptr;       // [11][stride] fp32
     __half* coeffs16 = nullptr;    // [7][stride]
@@ -1156,10 +1159,10 @@ const char* hydro_last_error(const hydro_t* h) { return h ? h->err : "null handl
 
 int64_t hydro_capacity(const hydro_t* h) { return h ? h->capacity : 0; }
 
-int hydro_set_scene(hydro_t* h, float water_density, float gravity)
+int hydro_set_scene(hydro_t* h, double water_density, double gravity)
 {
     if (!h) return HYDRO_E_ARG;
-    if (!(water_density >= 0.0f) || !(gravity == gravity)) return fail(h, HYDRO_E_ARG, "bad scene scalars");
+    if (!(water_density >= 0.0) || !(gravity == gravity)) return fail(h, HYDRO_E_ARG, "bad scene scalars");
     h->rho = water_density;
     h->g = gravity;
     return HYDRO_OK;

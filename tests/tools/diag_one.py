@@ -8,7 +8,7 @@ seed, law, i = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
 sc = (scenes.scene_c4 if law == "c4" else scenes.scene_c5)(n=262144, seed=seed, margin=None)
 lib = ctypes.CDLL(os.path.join(REPO, "tests", "host_emul", "libemul.so")); fp = ctypes.POINTER(ctypes.c_float)
 st = sc.state[i].copy(); pv = sc.prev[i].copy(); pr = sc.params[i].copy(); out = np.zeros(27, np.float32)
-lib.emul_body(st.ctypes.data_as(fp), pv.ctypes.data_as(fp), pr.ctypes.data_as(fp), ctypes.c_float(sc.rho), ctypes.c_float(sc.g), ctypes.c_float(np.float32(1/sc.dt)), out.ctypes.data_as(fp))
+lib.emul_body(st.ctypes.data_as(fp), pv.ctypes.data_as(fp), pr.ctypes.data_as(fp), ctypes.c_double(sc.rho), ctypes.c_double(sc.g), ctypes.c_float(np.float32(1/sc.dt)), out.ctypes.data_as(fp))
 acc = ho.finite_difference_accel(sc.state[i:i+1].astype(np.float64), sc.prev[i:i+1].astype(np.float64), sc.dt)
 comps, ratio = c_oracle.components(sc.state[i:i+1], acc, sc.params[i:i+1,:10], sc.rho, sc.g)
 c = comps[0]; p = sc.state[i,:3].astype(np.float64)
