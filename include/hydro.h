@@ -73,6 +73,20 @@ int64_t     hydro_capacity(const hydro_t *h);
  * cancel along z are evaluated in fp64 inside the kernels. */
 int hydro_set_scene(hydro_t *h, double water_density, double gravity);
 
+/* Which of the reference's two calculators the results follow where the two differ.  Default
+ * HYDRO_SEM_NUMBA: numba_hydrodynamics.py, the documented model and the parity target.
+ * HYDRO_SEM_WARP: warp_hydrodynamics.py, the twin hydrodynamics_behavior.py:155 actually instantiates:
+ *   - added mass rotates the world accelerations with R where Numba uses R^T
+ *     (warp_hydrodynamics.py:216-217 vs numba_hydrodynamics.py:229-230);
+ *   - component mode: a dry body reports cob = cop = its position (the mean of its wet keypoints if it has
+ *     any), not zeros (warp_hydrodynamics.py:59-61,290 vs numba_hydrodynamics.py:277-279).
+ * Everything else is common (same matrix from the quaternion - Warp's quat_rotate differs from it by
+ * 2(|q|^2-1), 2.4e-7 for an fp32-rounded unit quaternion; lift with a degenerate axis and the pressure
+ * centre at rest, which the Warp source leaves unassigned, follow Numba / the N1 completion). */
+#define HYDRO_SEM_NUMBA 0
+#define HYDRO_SEM_WARP  1
+int hydro_set_semantics(hydro_t *h, int semantics);
+
 /* Per-body constants: the remaining ten ctor arguments of the reference wrappers
  * (numba_hydrodynamics_wrapper.py:9-32) plus the rigid-body mass used by the clamp
  * (hydrodynamics_behavior.py:172-173,222).  `params[f]` points at n floats; `on_device` says
@@ -189,8 +203,10 @@ int hydro_step_fused_tiled(hydro_t *h, int64_t n, const float *state, int64_t st
                            float *wrench, int64_t wrench_tile_stride, int implicit_drag, void *stream);
 
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
- * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1). */
-int hydro_set_tuning(hydro_t *h, int bodies_per_lane, int block_threads, int non_temporal);
+ * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1), resident waves per
+ * SIMD of the tiled wrench kernel (-1 = chosen by size, 0 = whatever the registers allow, 1..8 = cap,
+ * enforced with a dynamic-LDS request: the kernel itself uses no LDS). */
+int hydro_set_tuning(hydro_t *h, int bodies_per_lane, int block_threads, int non_temporal, int waves_per_simd);
 
 int   hydro_sync(hydro_t *h);
 void *hydro_stream(hydro_t *h);

@@ -28,6 +28,11 @@ Documented completion: the reference's
 :113-115 - is `(center_of_buoyancy, 0.0)`; this oracle, the golden generator
 and the HIP kernels all apply that completion.
 
+Warp twin (`semantics="warp"`): the two places where warp_hydrodynamics.py:233-335 differs from the
+Numba path (added-mass rotation, centres of a dry body) are restated from its source text.  PARITY
+UNPINNED for that mode: `warp` is not importable in the build container and the reference holds no
+outputs of it, so nothing executes or pins the Warp path; the Numba mode is unaffected.
+
 Field orders used everywhere in this repo
   state  (13): px py pz | qx qy qz qw | vx vy vz | wx wy wz     (quat xyzw)
   prev    (6): vx vy vz | wx wy wz      (velocity at the previous step)
@@ -188,20 +193,25 @@ def lift_force(speed, vel_dir, rot, area, rho, lift_coeff, ratio):
     return mag * direction * ratio
 
 
-def added_mass(ratio, a, alpha, rot, diag):
-    """-M * body-frame acceleration, rotated back (numba_hydrodynamics.py:220-253)."""
+def added_mass(ratio, a, alpha, rot, diag, semantics="numba"):
+    """-M * body-frame acceleration, rotated back (numba_hydrodynamics.py:220-253).
+    semantics="warp": the Warp twin rotates the world accelerations with quat_rotate(q, .) = R
+    instead of R^T (warp_hydrodynamics.py:216-217); everything else is the same."""
     if ratio <= DRY_EPS:
         return np.zeros(3), np.zeros(3)
-    a_b = rot.T @ a
-    al_b = rot.T @ alpha
+    to_local = rot if semantics == "warp" else rot.T
+    a_b = to_local @ a
+    al_b = to_local @ alpha
     f_b = -diag[:3] * a_b
     t_b = -diag[3:] * al_b
     return (rot @ f_b) * ratio, (rot @ t_b) * ratio
 
 
-def solve_components_one(p, q, v, w, a, alpha, params, rho, g):
+def solve_components_one(p, q, v, w, a, alpha, params, rho, g, semantics="numba"):
     """One body, 9 outputs in the reference's order
-    (numba_hydrodynamics.py:256-314).  `params` = the 11 PARAM_FIELDS."""
+    (numba_hydrodynamics.py:256-314).  `params` = the 11 PARAM_FIELDS.
+    semantics="warp": warp_hydrodynamics.py:233-335 where it differs (added mass, N3; a dry body
+    reports cob = cop = centre of its wet keypoints or its position, N6)."""
     p, q, v, w, a, alpha = (np.asarray(x, dtype=np.float64) for x in (p, q, v, w, a, alpha))
     dims = np.asarray(params[:3], dtype=np.float64)
     cd_lin, cd_ang, damp_lin, damp_ang, lift_c, am_lin, am_ang = (float(x) for x in params[3:10])
@@ -212,6 +222,8 @@ def solve_components_one(p, q, v, w, a, alpha, params, rho, g):
     ratio, cob = submersion_and_cob(world, p)
     if ratio <= DRY_EPS:
         z3 = np.zeros(3)
+        if semantics == "warp":                # warp_hydrodynamics.py:58-61,283-290: outputs initialised, cop = cob
+            return tuple(z3.copy() for _ in range(6)) + (cob.copy(), cob.copy(), 0.0)
         return tuple(z3.copy() for _ in range(8)) + (0.0,)
 
     buoy = np.array([0.0, 0.0, rho * (ratio * volume) * g])
@@ -222,7 +234,7 @@ def solve_components_one(p, q, v, w, a, alpha, params, rho, g):
                                  cd_lin, damp_lin, v, cd_ang, damp_ang, w)
     lift_f = lift_force(speed, vel_dir, rot, area, rho, lift_c, ratio)
     am_f, am_t = added_mass(ratio, a, alpha, rot,
-                            added_mass_diagonal(dims, rho, am_lin, am_ang))
+                            added_mass_diagonal(dims, rho, am_lin, am_ang), semantics)
     return buoy, drag_f, lift_f, drag_t, am_f, am_t, cob, cop, ratio
 
 
@@ -260,8 +272,8 @@ _LATTICE_IJK = np.array([(i, j, k) for k in (1, 0, -1) for j in (1, 0, -1) for i
                         dtype=np.float64)  # (27,3)
 
 
-def solve_components(state, accel, params, rho, g):
-    """Vectorised A1-A11.
+def solve_components(state, accel, params, rho, g, semantics="numba"):
+    """Vectorised A1-A11 (semantics as in `solve_components_one`).
 
     state  (N,13) float64, accel (N,6) [a | alpha], params (N,11).
     Returns dict with the eight (N,3) COMPONENT_FIELDS plus 'ratio' (N,) and
@@ -349,8 +361,9 @@ def solve_components(state, accel, params, rho, g):
     m_ang = np.stack([volume * (dims[:, 1] ** 2 + dims[:, 2] ** 2) * am_ang * rho,
                       volume * (dims[:, 0] ** 2 + dims[:, 2] ** 2) * am_ang * rho,
                       volume * (dims[:, 0] ** 2 + dims[:, 1] ** 2) * am_ang * rho], axis=1)
-    a_b = np.einsum("nba,nb->na", rot, a)
-    al_b = np.einsum("nba,nb->na", rot, alpha)
+    to_local = "nab,nb->na" if semantics == "warp" else "nba,nb->na"     # N3: R (Warp) / R^T (Numba)
+    a_b = np.einsum(to_local, rot, a)
+    al_b = np.einsum(to_local, rot, alpha)
     am_f = np.einsum("nab,nb->na", rot, -lin[:, None] * a_b) * ratio[:, None]
     am_t = np.einsum("nab,nb->na", rot, -m_ang * al_b) * ratio[:, None]
 
@@ -360,6 +373,10 @@ def solve_components(state, accel, params, rho, g):
         "center_of_buoyancy": cob, "center_of_pressure": cop,
     }
     for k in out:                       # A4: dry bodies return zeros for everything
+        if semantics == "warp" and k in ("center_of_buoyancy", "center_of_pressure"):
+            # N6: cob as computed (position, or mean of the wet keypoints), cop = cob
+            out[k] = np.where(live[:, None], out[k], cob)
+            continue
         out[k] = np.where(live[:, None], out[k], 0.0)
     out["ratio"] = np.where(live, ratio, 0.0)
     out["area"] = np.where(live, area, 0.0)
@@ -389,14 +406,14 @@ def behavior_epilogue(position, comps, mass):
     return net_f * scale[:, None], net_t * scale[:, None], scale
 
 
-def step_wrench(state, prev, params, rho, g, dt):
+def step_wrench(state, prev, params, rho, g, dt, semantics="numba"):
     """The fused entry point the HIP path implements: A13 + A1-A11 + A14 + A15.
 
     Returns (net_force (N,3), net_torque (N,3), aux dict)."""
     state = np.asarray(state, dtype=np.float64)
     params = np.asarray(params, dtype=np.float64)
     accel = finite_difference_accel(state, prev, dt)
-    comps = solve_components(state, accel, params, rho, g)
+    comps = solve_components(state, accel, params, rho, g, semantics)
     net_f, net_t, scale = behavior_epilogue(state[:, 0:3], comps, params[:, 10])
     comps["scale"] = scale
     return net_f, net_t, comps

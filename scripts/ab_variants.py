@@ -40,8 +40,21 @@ for kind, n, coeff, sets in (("c5", 1048576, "f16", 4), ("c5", 1048576, "f32", 4
     sc = bench.build_scene(kind, n, 11)
     reps = {}
     for nm in names:
-        nat._lib = nat.load(so(nm))           # HydroEngine binds whatever nat.load() returns
+        import ctypes
+        libname, _, opt = nm.partition("@")          # "new@w5b128": lib "new", 5 waves/SIMD cap, 128-thread blocks
+        raw = ctypes.CDLL(so(libname)); full = dict(nat.SIGNATURES)
+        for k in [k for k in full if not hasattr(raw, k)]:       # older builds lack newer entry points
+            del nat.SIGNATURES[k]
+        nat._lib = nat.load(so(libname))      # HydroEngine binds whatever nat.load() returns
+        nat.SIGNATURES.update(full)
+        if not hasattr(nat._lib, "hydro_set_semantics"):
+            HydroEngine.set_semantics = lambda self, *_a, **_k: None
         reps[nm] = [bench.Replica(sc, coeff, dev, roll=7919 * k) for k in range(sets)]
+        if opt:
+            import re
+            w = re.search(r"w(\d)", opt); b = re.search(r"b(\d+)", opt)
+            for R in reps[nm]:
+                R.engine.set_tuning(0, int(b.group(1)) if b else 0, -1, int(w.group(1)) if w else -1)
     outs = {nm: reps[nm][0] for nm in names}
     with torch.cuda.stream(stream):
         for nm in names: reps[nm][0].step()

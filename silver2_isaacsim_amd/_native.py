@@ -18,6 +18,7 @@ STATE_FIELDS, PREV_FIELDS, PARAM_FIELDS, WRENCH_FIELDS, COMP_FIELDS = 13, 6, 11,
 TILE = 64
 
 HYDRO_OK = 0
+HYDRO_SEM_NUMBA, HYDRO_SEM_WARP = 0, 1
 STATUS_NAMES = {0: "HYDRO_OK", -1: "HYDRO_E_ARG", -2: "HYDRO_E_ALLOC", -3: "HYDRO_E_LAUNCH",
                 -4: "HYDRO_E_DEVICE", -5: "HYDRO_E_STATE"}
 
@@ -32,6 +33,7 @@ SIGNATURES = {
     "hydro_last_error": (c_char_p, [c_void_p]),
     "hydro_capacity": (c_int64, [c_void_p]),
     "hydro_set_scene": (c_int, [c_void_p, c_double, c_double]),
+    "hydro_set_semantics": (c_int, [c_void_p, c_int]),
     "hydro_set_params_f32": (c_int, [c_void_p, c_int64, _FP, c_int]),
     "hydro_set_params_f16": (c_int, [c_void_p, c_int64, _FP, c_int]),
     "hydro_reset_prev_velocity": (c_int, [c_void_p]),
@@ -55,7 +57,7 @@ SIGNATURES = {
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
     "hydro_kinetic_energy_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
-    "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "hydro_sync": (c_int, [c_void_p]),
     "hydro_stream": (c_void_p, [c_void_p]),
 }

@@ -121,7 +121,9 @@ struct BodyOut {
 // A1-A11.  rho, g are scene scalars (hydrodynamics_config.json:2-5 "globals").
 // They arrive as doubles (the reference passes Python floats, numba_hydrodynamics_wrapper.py:9-10): 9.81 is
 // not an fp32 number, and rounding it costs 4e-8 of the buoyancy before any arithmetic has happened.
-HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64)
+// `warp` (uniform over a launch) selects the semantics of the reference's Warp twin where it differs from
+// the Numba path (include/hydro.h HYDRO_SEM_WARP); the default is Numba.
+HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp = false)
 {
     const float rho = (float)rho64, g = (float)g64;
     BodyOut o;
@@ -355,6 +357,27 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64)
     const float kf = -m_lin * ratio;
     const float kt = -m_ang * ratio;
     const float tlx = kt * (d2y + d2z) * bbx, tly = kt * (d2x + d2z) * bby, tlz = kt * (d2x + d2y) * bbz;
+    float am_fx = kf * (one2e * b.ax - qe * sax), am_fy = kf * (one2e * b.ay - qe * say), am_fz = kf * (one2e * b.az - qe * saz);
+    float am_tx = r00 * tlx + r01 * tly + r02 * tlz;
+    float am_ty = r10 * tlx + r11 * tly + r12 * tlz;
+    float am_tz = r20 * tlx + r21 * tly + r22 * tlz;
+    if (warp) {
+        // N3: the Warp twin takes the world accelerations into the "local" frame with quat_rotate(q, .) = R
+        // (warp_hydrodynamics.py:216-217) where Numba uses R^T (numba_hydrodynamics.py:229-230), and comes
+        // back with R in both (:229-230 / :247-248):  F = R (-M (R a)).  Reproduced as written.
+        const float alx = r00 * b.ax + r01 * b.ay + r02 * b.az;
+        const float aly = r10 * b.ax + r11 * b.ay + r12 * b.az;
+        const float alz = r20 * b.ax + r21 * b.ay + r22 * b.az;
+        am_fx = kf * (r00 * alx + r01 * aly + r02 * alz);
+        am_fy = kf * (r10 * alx + r11 * aly + r12 * alz);
+        am_fz = kf * (r20 * alx + r21 * aly + r22 * alz);
+        const float wlx = kt * (d2y + d2z) * (r00 * b.bx + r01 * b.by + r02 * b.bz);
+        const float wly = kt * (d2x + d2z) * (r10 * b.bx + r11 * b.by + r12 * b.bz);
+        const float wlz = kt * (d2x + d2y) * (r20 * b.bx + r21 * b.by + r22 * b.bz);
+        am_tx = r00 * wlx + r01 * wly + r02 * wlz;
+        am_ty = r10 * wlx + r11 * wly + r12 * wlz;
+        am_tz = r20 * wlx + r21 * wly + r22 * wlz;
+    }
 
     // ---- A4: dry bodies return zeros for every output (:277-279) ----
     // (selects, not multiplies: a dry body must give exact zeros whatever the rest evaluated to)
@@ -366,16 +389,16 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64)
     o.lift_fx = HYDRO_LIVE(lift_k * (r02 * vhat2 + d_raw * dx));
     o.lift_fy = HYDRO_LIVE(lift_k * (r12 * vhat2 + d_raw * dy));
     o.lift_fz = HYDRO_LIVE(lift_k * (r22 * vhat2 + d_raw * dz));
-    o.am_fx = HYDRO_LIVE(kf * (one2e * b.ax - qe * sax));
-    o.am_fy = HYDRO_LIVE(kf * (one2e * b.ay - qe * say));
-    o.am_fz = HYDRO_LIVE(kf * (one2e * b.az - qe * saz));
-    o.am_tx = HYDRO_LIVE(r00 * tlx + r01 * tly + r02 * tlz);
-    o.am_ty = HYDRO_LIVE(r10 * tlx + r11 * tly + r12 * tlz);
-    o.am_tz = HYDRO_LIVE(r20 * tlx + r21 * tly + r22 * tlz);
+    o.am_fx = HYDRO_LIVE(am_fx); o.am_fy = HYDRO_LIVE(am_fy); o.am_fz = HYDRO_LIVE(am_fz);
+    o.am_tx = HYDRO_LIVE(am_tx); o.am_ty = HYDRO_LIVE(am_ty); o.am_tz = HYDRO_LIVE(am_tz);
     o.fz_core = HYDRO_LIVE(fz_core); o.tbx = HYDRO_LIVE(tbx); o.tby = HYDRO_LIVE(tby);
     o.lin_k = HYDRO_LIVE(lin_k); o.ang_k = HYDRO_LIVE(ang_k);
-    o.armb_x = HYDRO_LIVE(armb_x); o.armb_y = HYDRO_LIVE(armb_y); o.armb_z = HYDRO_LIVE(armb_z);
-    o.armp_x = HYDRO_LIVE(armp_x); o.armp_y = HYDRO_LIVE(armp_y); o.armp_z = HYDRO_LIVE(armp_z);
+    // N6: a dry body's centres are zeros in Numba (:277-279); the Warp twin reports cob (the position, or the
+    // mean of whatever keypoints are wet) and cop = cob (warp_hydrodynamics.py:59-61,290) - component mode only,
+    // every force is zero either way.
+    const bool arms = wet || warp;
+    o.armb_x = arms ? armb_x : 0.0f; o.armb_y = arms ? armb_y : 0.0f; o.armb_z = arms ? armb_z : 0.0f;
+    o.armp_x = wet ? armp_x : o.armb_x; o.armp_y = wet ? armp_y : o.armb_y; o.armp_z = wet ? armp_z : o.armb_z;
     const float ks = lin_k * speed;                                 // drag_force = ks * v_hat
     o.dragarm_tx = HYDRO_LIVE(ks * pxv_x); o.dragarm_ty = HYDRO_LIVE(ks * pxv_y); o.dragarm_tz = HYDRO_LIVE(ks * pxv_z);
 #undef HYDRO_LIVE

@@ -44,6 +44,21 @@ __device__ __forceinline__ T* at(void* __restrict__ p, uint32_t byte_off)
     return reinterpret_cast<T*>(static_cast<char*>(p) + byte_off);
 }
 
+// base + per-lane offset + compile-time field offset.  The field offset is added AFTER the 32-bit lane offset
+// has been zero-extended (pointer arithmetic), so it lands in the load instruction's immediate
+// (global_load_dword v, voff, s[base] offset:f*256); written as `voff + f*256` in 32 bits the compiler must
+// keep the wrap-around semantics and spends one v_add_u32 + one VGPR per field.
+template <typename T>
+__device__ __forceinline__ const T* at(const void* __restrict__ p, uint32_t lane_off, uint32_t field_off)
+{
+    return reinterpret_cast<const T*>(static_cast<const char*>(p) + lane_off + field_off);
+}
+template <typename T>
+__device__ __forceinline__ T* at(void* __restrict__ p, uint32_t lane_off, uint32_t field_off)
+{
+    return reinterpret_cast<T*>(static_cast<char*>(p) + lane_off + field_off);
+}
+
 // NT = non-temporal (streaming) access: every byte of a large scene is touched once per step,
 // so nothing is worth keeping in L2 / Infinity Cache; measured +5..9 % on the SoA kernel.
 template <bool NT, typename V>
@@ -128,13 +143,14 @@ struct SoaArgs {
     float* out[HYDRO_WRENCH_FIELDS];
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
     float inv_dt;
+    int warp;                                // HYDRO_SEM_WARP (uniform)
     int64_t n;
 };
 
 // One body from already-loaded scalars.
 __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
                                                      const float (&d)[3], const float (&c)[7], float mass,
-                                                     double rho, double g, float inv_dt)
+                                                     double rho, double g, float inv_dt, bool warp)
 {
     hydro::BodyIn b;
     b.px = s[0]; b.py = s[1]; b.pz = s[2];
@@ -147,14 +163,14 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
     b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
     b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body(b, rho, g);
+    const hydro::BodyOut o = hydro::solve_body(b, rho, g, warp);
     return hydro::assemble_wrench(o, mass);
 }
 
 // Same, also handing back the (clamped) linear / angular drag coefficients for the implicit integrator.
 __device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
                                                        const float (&d)[3], const float (&c)[7], float mass,
-                                                       double rho, double g, float inv_dt, float& k_lin, float& k_ang)
+                                                       double rho, double g, float inv_dt, bool warp, float& k_lin, float& k_ang)
 {
     hydro::BodyIn b;
     b.px = s[0]; b.py = s[1]; b.pz = s[2];
@@ -166,7 +182,7 @@ __device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_ST
     b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
     b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body(b, rho, g);
+    const hydro::BodyOut o = hydro::solve_body(b, rho, g, warp);
     const hydro::Wrench w = hydro::assemble_wrench(o, mass);
     k_lin = o.lin_k * w.scale;
     k_ang = o.ang_k * w.scale;
@@ -211,7 +227,7 @@ __global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
         for (int f = 0; f < 3; ++f) d[f] = dm[f][j];
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = cf[f][j];
-        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt);
+        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, a.warp != 0);
         out[0][j] = w.fx; out[1][j] = w.fy; out[2][j] = w.fz;
         out[3][j] = w.tx; out[4][j] = w.ty; out[5][j] = w.tz;
     }
@@ -245,6 +261,7 @@ struct TiledArgs {
     float* out;       uint32_t out_stride;     // 6 fields
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
     float inv_dt;
+    int warp;                                // HYDRO_SEM_WARP (uniform)
     uint32_t n;
 };
 // fp16-coefficient parameter record per tile: [dimx dimy dimz mass][64] f32 (1024 B) then
@@ -263,33 +280,33 @@ __global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
     const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
 #pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so + f * 256u));
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so, f * 256u));
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
     if constexpr (HALF) {
         const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
         const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
     } else {
         const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
     }
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
     const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
-    stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo + 256u), w.fy); stg<NT>(at<float>(a.out, oo + 512u), w.fz);
-    stg<NT>(at<float>(a.out, oo + 768u), w.tx); stg<NT>(at<float>(a.out, oo + 1024u), w.ty); stg<NT>(at<float>(a.out, oo + 1280u), w.tz);
+    stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
+    stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
     if constexpr (WRITE_PREV) {
         const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo + f * 256u), s[7 + f]);
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo, f * 256u), s[7 + f]);
     }
 }
 
@@ -408,6 +425,7 @@ struct AosArgs {
     const float* prm;       // engine-owned parameters, tiled record (f32 or fp16-coefficient form)
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
     float inv_dt;
+    int warp;                                // HYDRO_SEM_WARP (uniform)
     int64_t n;
 };
 
@@ -463,29 +481,29 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
     const uint32_t tile = ic >> 6, tl = ic & 63u;                  // w0 is a multiple of 64: tile == this wave's tile
     const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + tl) * 4u;
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
     if constexpr (HALF) {
         const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + tl * 4u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
         const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + tl * 2u;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
     } else {
         const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + tl * 4u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
     }
 
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
 
     if (live) {
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv, po + f * 256u), s[7 + f]);
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv, po, f * 256u), s[7 + f]);
     }
     wave_lds_fence();                                              // every lane has read its velocity
     lds[3 * lane] = w.fx; lds[3 * lane + 1] = w.fy; lds[3 * lane + 2] = w.fz;
@@ -515,6 +533,7 @@ struct CompArgs {
     float* out[HYDRO_COMP_FIELDS];
     float* ratio;
     double rho, g;
+    int warp;
     int64_t n;
 };
 
@@ -535,8 +554,8 @@ __global__ void __launch_bounds__(kBlock) components_kernel(const CompArgs a)
     b.damp_lin = load_coef1<HALF>(a.coef[2], i); b.damp_ang = load_coef1<HALF>(a.coef[3], i);
     b.lift = load_coef1<HALF>(a.coef[4], i); b.am_lin = load_coef1<HALF>(a.coef[5], i);
     b.am_ang = load_coef1<HALF>(a.coef[6], i);
-    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g);
-    const float live = o.wet ? 1.0f : 0.0f;
+    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g, a.warp != 0);
+    const float live = (o.wet || a.warp != 0) ? 1.0f : 0.0f;     // centres of a dry body: zeros (Numba) / position (Warp), N6
     a.out[0][i] = 0.0f; a.out[1][i] = 0.0f; a.out[2][i] = o.buoy_z;
     a.out[3][i] = o.drag_fx; a.out[4][i] = o.drag_fy; a.out[5][i] = o.drag_fz;
     a.out[6][i] = o.lift_fx; a.out[7][i] = o.lift_fy; a.out[8][i] = o.lift_fz;
@@ -559,6 +578,7 @@ struct CompAosArgs {
     float* out[8];                                               // eight (n,3) tensors, reference order
     float* ratio;
     double rho, g;
+    int warp;
     uint32_t n;
 };
 
@@ -579,19 +599,19 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
     float c[7];
     if constexpr (HALF) {
         const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
-        b.dimx = *at<float>(a.prm, qo); b.dimy = *at<float>(a.prm, qo + 256u); b.dimz = *at<float>(a.prm, qo + 512u);
+        b.dimx = *at<float>(a.prm, qo); b.dimy = *at<float>(a.prm, qo, 256u); b.dimz = *at<float>(a.prm, qo, 512u);
         const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(*at<unsigned short>(a.prm, ho + f * 128u));
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(*at<unsigned short>(a.prm, ho, f * 128u));
     } else {
         const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
-        b.dimx = *at<float>(a.prm, qo); b.dimy = *at<float>(a.prm, qo + 256u); b.dimz = *at<float>(a.prm, qo + 512u);
+        b.dimx = *at<float>(a.prm, qo); b.dimy = *at<float>(a.prm, qo, 256u); b.dimz = *at<float>(a.prm, qo, 512u);
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = *at<float>(a.prm, qo + (3 + f) * 256u);
     }
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3]; b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g);
-    const float live = o.wet ? 1.0f : 0.0f;
+    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g, a.warp != 0);
+    const float live = (o.wet || a.warp != 0) ? 1.0f : 0.0f;     // N6
     const float v[8][3] = {{0.0f, 0.0f, o.buoy_z}, {o.drag_fx, o.drag_fy, o.drag_fz}, {o.lift_fx, o.lift_fy, o.lift_fz},
                            {o.drag_tx, o.drag_ty, o.drag_tz}, {o.am_fx, o.am_fy, o.am_fz}, {o.am_tx, o.am_ty, o.am_tz},
                            {live * (b.px + o.armb_x), live * (b.py + o.armb_y), live * (b.pz + o.armb_z)},
@@ -799,39 +819,39 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArg
     const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
 #pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so + f * 256u));
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so, f * 256u));
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po + f * 256u));
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
     if constexpr (HALF) {
         const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo + 3 * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
         const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho + f * 128u)));
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
     } else {
         const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo + f * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo + 10 * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
     }
     float k_lin = 0.0f, k_ang = 0.0f;
     hydro::Wrench w;
-    if constexpr (IMPLICIT) w = body_wrench_k(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, k_lin, k_ang);
-    else w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt);
+    if constexpr (IMPLICIT) w = body_wrench_k(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0, k_lin, k_ang);
+    else w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
     const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
     float o[HYDRO_STATE_FIELDS];
     integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, k_lin, k_ang, o);
     const uint32_t oo = (__umul24(tile, fa.so_stride) + lane) * 4u;
 #pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(fa.so, oo + f * 256u), o[f]);
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(fa.so, oo, f * 256u), o[f]);
     if (a.out) {
         const uint32_t wo = (__umul24(tile, a.out_stride) + lane) * 4u;
 #pragma unroll
-        for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(a.out, wo + f * 256u), f6[f]);
+        for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(a.out, wo, f * 256u), f6[f]);
     }
 }
 
@@ -852,6 +872,7 @@ struct hydro_engine {
     int64_t stride = 0;            // padded field stride of the engine-owned SoA buffers (floats)
     int64_t n_params = 0;          // bodies for which parameters have been set
     double rho = 1025.0, g = 9.81;
+    int semantics = HYDRO_SEM_NUMBA;
     bool half_coeffs = false;
     float* params = nullptr;       // [11][stride] fp32
     __half* coeffs16 = nullptr;    // [7][stride]
@@ -863,6 +884,7 @@ struct hydro_engine {
     int vec = 0;                   // bodies per lane, 0 = default (1)
     int block = 0;                 // threads per block, 0 = by size
     int nt = -1;                   // non-temporal accesses: -1 = by size, 0 = off, 1 = on
+    int waves = -1;                // resident waves per SIMD of the tiled wrench kernel: -1 = by size, 0 = no cap
     // the engine-owned previous velocity exists in both layouts; which copy is current:
     enum PrevCopy { kPrevBoth, kPrevSoa, kPrevTiled } prev_current = kPrevBoth;
     char err[512] = {0};
@@ -995,7 +1017,7 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
     }
     fill_params(h, a);
     a.mass = h->params + 10 * h->stride;
-    a.rho = h->rho; a.g = h->g;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics;
     a.inv_dt = (float)(1.0 / (double)dt);
     a.n = n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
@@ -1266,14 +1288,23 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
     else { a.pv = prev; a.pv_stride = (uint32_t)prev_tile_stride; a.pv_out = nullptr; a.pvo_stride = 0; }
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = (uint32_t)wrench_tile_stride;
-    a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (own_prev && (rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
     const int block = h->block ? h->block : 256;
     const dim3 grid(grid_for(n, block)), blk(block);
-#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, 0, s, a)
+    // Occupancy shaping: the kernel uses no LDS, so a dynamic-LDS request is a pure residency cap
+    // (160 KB per CU / blocks per CU).  Fewer resident waves = fewer DRAM streams in flight.
+    const int waves = h->waves < 0 ? 0 : h->waves;
+    size_t lds = 0;
+    if (waves > 0) {
+        const int blocks_per_cu = (waves * 4 * 64) / block;                 // 4 SIMDs x waves x 64 lanes
+        lds = blocks_per_cu > 0 ? ((size_t)160 * 1024 / (size_t)blocks_per_cu) & ~(size_t)255 : 0;
+        if (lds > 64 * 1024) lds = 64 * 1024;                               // per-block LDS limit
+    }
+#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, lds, s, a)
 #define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
 #define HYDRO_TILED_WP(BLOCK, HALF) do { if (own_prev) HYDRO_TILED_NT(BLOCK, HALF, true); else HYDRO_TILED_NT(BLOCK, HALF, false); } while (0)
 #define HYDRO_TILED_HALF(BLOCK) do { if (h->half_coeffs) HYDRO_TILED_WP(BLOCK, true); else HYDRO_TILED_WP(BLOCK, false); } while (0)
@@ -1330,7 +1361,7 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     a.pv = prev; a.pv_stride = (uint32_t)prev_tile_stride; a.pv_out = nullptr; a.pvo_stride = 0;
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = wrench ? (uint32_t)wrench_tile_stride : 0;
-    a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
     fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = dt;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1412,7 +1443,7 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     a.pos = positions; a.quat = orientations; a.quat_xyzw = quat_xyzw ? 1 : 0; a.vel = velocities; a.force = forces; a.torque = torques;
     if (n > ((int64_t)1 << 26)) return fail(h, HYDRO_E_ARG, "array-of-structs entry handles at most 2^26 bodies per call");
     a.pv = h->prev_tiled; a.prm = h->params_tiled;
-    a.rho = h->rho; a.g = h->g; a.inv_dt = (float)(1.0 / (double)dt); a.n = n;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
@@ -1442,7 +1473,7 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) { if (!accel[f]) return fail(h, HYDRO_E_ARG, "null acceleration field"); a.acc[f] = accel[f]; }
     for (int f = 0; f < HYDRO_COMP_FIELDS; ++f) { if (!comps[f]) return fail(h, HYDRO_E_ARG, "null component field"); a.out[f] = comps[f]; }
     fill_params(h, a);
-    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.n = n;
+    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n, kBlock);
@@ -1481,7 +1512,7 @@ int hydro_step_components_aos(hydro_t* h, int64_t n, const float* position, cons
     a.pos = position; a.quat_xyzw = orientation_xyzw; a.lin_vel = linear_vel; a.ang_vel = angular_vel;
     a.lin_acc = linear_accel; a.ang_acc = angular_accel; a.prm = h->params_tiled;
     for (int k = 0; k < 8; ++k) { if (!out[k]) return fail(h, HYDRO_E_ARG, "null output tensor"); a.out[k] = out[k]; }
-    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.n = (uint32_t)n;
+    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = (uint32_t)n;
     HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n, kBlock);
@@ -1542,7 +1573,16 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
     return HYDRO_OK;
 }
 
-int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads, int non_temporal)
+int hydro_set_semantics(hydro_t* h, int semantics)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (semantics != HYDRO_SEM_NUMBA && semantics != HYDRO_SEM_WARP)
+        return fail(h, HYDRO_E_ARG, "semantics must be HYDRO_SEM_NUMBA (0) or HYDRO_SEM_WARP (1)");
+    h->semantics = semantics;
+    return HYDRO_OK;
+}
+
+int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads, int non_temporal, int waves_per_simd)
 {
     if (!h) return HYDRO_E_ARG;
     if (!(bodies_per_lane == 0 || bodies_per_lane == 1 || bodies_per_lane == 2))
@@ -1550,9 +1590,11 @@ int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads, int non
     if (!(block_threads == 0 || block_threads == 128 || block_threads == 256))
         return fail(h, HYDRO_E_ARG, "block_threads must be 0, 128 or 256");
     if (non_temporal < -1 || non_temporal > 1) return fail(h, HYDRO_E_ARG, "non_temporal must be -1, 0 or 1");
+    if (waves_per_simd < -1 || waves_per_simd > 8) return fail(h, HYDRO_E_ARG, "waves_per_simd must be -1 .. 8");
     h->vec = bodies_per_lane;
     h->block = block_threads;
     h->nt = non_temporal;
+    h->waves = waves_per_simd;
     return HYDRO_OK;
 }
 

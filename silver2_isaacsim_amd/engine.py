@@ -50,6 +50,7 @@ class HydroEngine:
             raise HydroError(rc, f"hydro_create(device={self.device.index}, capacity={capacity}) failed")
         self.n = 0
         self.coeff_dtype = "f32"
+        self.semantics = "numba"
         self._tables: dict = {}
         self.set_scene(water_density, gravity)
 
@@ -84,6 +85,15 @@ class HydroEngine:
         self.water_density, self.gravity = float(water_density), float(gravity)
         self._check(self._lib.hydro_set_scene(self._h, self.water_density, self.gravity))
 
+    def set_semantics(self, semantics: str = "numba") -> None:
+        """'numba' (default, the parity target) or 'warp': follow the reference's Warp twin where the two
+        calculators differ (added-mass rotation, centres of a dry body; include/hydro.h)."""
+        code = {"numba": nat.HYDRO_SEM_NUMBA, "warp": nat.HYDRO_SEM_WARP}.get(semantics)
+        if code is None:
+            raise ValueError("semantics must be 'numba' or 'warp'")
+        self._check(self._lib.hydro_set_semantics(self._h, code))
+        self.semantics = semantics
+
     def set_params(self, params, coeff_dtype: str = "f32") -> None:
         """Per-body constants, (N,11) or (11,N): dims(3), cd_lin, cd_ang, damp_lin, damp_ang,
         lift, am_lin, am_ang, mass.  coeff_dtype 'f16' stores the seven coefficients as half."""
@@ -95,8 +105,9 @@ class HydroEngine:
         self.n = n
         self.coeff_dtype = coeff_dtype
 
-    def set_tuning(self, bodies_per_lane: int = 0, block_threads: int = 0, non_temporal: int = -1) -> None:
-        self._check(self._lib.hydro_set_tuning(self._h, bodies_per_lane, block_threads, non_temporal))
+    def set_tuning(self, bodies_per_lane: int = 0, block_threads: int = 0, non_temporal: int = -1,
+                   waves_per_simd: int = -1) -> None:
+        self._check(self._lib.hydro_set_tuning(self._h, bodies_per_lane, block_threads, non_temporal, waves_per_simd))
 
     # ------------------------------------------------- previous-velocity state
     def reset_prev_velocity(self) -> None:

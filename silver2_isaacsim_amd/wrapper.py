@@ -13,8 +13,10 @@ Return convention follows the Warp wrapper, which is what the behavior script
 consumes (hydrodynamics_behavior.py:205-209): eight float32 device tensors of
 shape (N,3) that are views of wrapper-owned buffers, valid until the next call
 (warp_hydrodynamics_wrapper.py:123-132).  Values follow the Numba path where the
-two references disagree (SURVEY.md notes N3, N4, N6).  The ninth value of the
-Numba tuple, the submersion ratio, is kept in `self.sub_ratio`.
+two references disagree (SURVEY.md notes N3, N4, N6) unless `semantics="warp"` is
+passed, which reproduces the Warp twin's added-mass rotation (N3) and dry-body
+centres (N6) instead.  The ninth value of the Numba tuple, the submersion ratio,
+is kept in `self.sub_ratio`.
 """
 from __future__ import annotations
 
@@ -40,7 +42,7 @@ def _column(x, n: int, name: str) -> np.ndarray:
 class HipHydrodynamicsWrapper:
     def __init__(self, width, depth, height, linear_drag_coefficient, angular_drag_coefficient, linear_damping,
                  angular_damping, water_density, gravity, linear_mass_coeff, angular_mass_coeff, lift_coefficient,
-                 device="cuda:0", mass=None, coeff_dtype: str = "f32"):
+                 device="cuda:0", mass=None, coeff_dtype: str = "f32", semantics: str = "numba"):
         args = dict(zip(_CTOR_ORDER, (width, depth, height, linear_drag_coefficient, angular_drag_coefficient,
                                       linear_damping, angular_damping, water_density, gravity,
                                       linear_mass_coeff, angular_mass_coeff, lift_coefficient)))
@@ -72,6 +74,7 @@ class HipHydrodynamicsWrapper:
                            self.lift_coefficient, self.linear_mass_coeff, self.angular_mass_coeff, self.mass], axis=0)
         self._engine = HydroEngine(n, self.device, self.water_density, self.gravity)
         self._engine.set_params(params.astype(np.float32), coeff_dtype)
+        self._engine.set_semantics(semantics)
         dev = self._engine.device
         self._comps_aos = torch.empty((8, n, 3), dtype=torch.float32, device=dev)
         self._ratio = torch.empty((n,), dtype=torch.float32, device=dev)

@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "../../silver2_isaacsim_amd/csrc/hydro_body.h"
 
+// 0 = Numba semantics (default), 1 = the Warp twin's (include/hydro.h HYDRO_SEM_*)
+static int g_warp = 0;
+extern "C" void emul_set_semantics(int warp) { g_warp = warp; }
+
 extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, const float* params,
                            double rho64, double g64, float inv_dt, float* net_f, float* net_t, float* ratio)
 {
@@ -16,7 +20,7 @@ extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, con
         b.bx = (b.wx - pv[3]) * inv_dt; b.by = (b.wy - pv[4]) * inv_dt; b.bz = (b.wz - pv[5]) * inv_dt;
         b.dimx = pr[0]; b.dimy = pr[1]; b.dimz = pr[2]; b.cd_lin = pr[3]; b.cd_ang = pr[4];
         b.damp_lin = pr[5]; b.damp_ang = pr[6]; b.lift = pr[7]; b.am_lin = pr[8]; b.am_ang = pr[9];
-        const hydro::BodyOut o = hydro::solve_body(b, rho64, g64);
+        const hydro::BodyOut o = hydro::solve_body(b, rho64, g64, g_warp != 0);
         const hydro::Wrench w = hydro::assemble_wrench(o, pr[10]);
         net_f[3 * i] = w.fx; net_f[3 * i + 1] = w.fy; net_f[3 * i + 2] = w.fz;
         net_t[3 * i] = w.tx; net_t[3 * i + 1] = w.ty; net_t[3 * i + 2] = w.tz;
@@ -36,7 +40,7 @@ extern "C" int emul_body(const float* s, const float* pv, const float* pr, doubl
     b.bx = (b.wx - pv[3]) * inv_dt; b.by = (b.wy - pv[4]) * inv_dt; b.bz = (b.wz - pv[5]) * inv_dt;
     b.dimx = pr[0]; b.dimy = pr[1]; b.dimz = pr[2]; b.cd_lin = pr[3]; b.cd_ang = pr[4];
     b.damp_lin = pr[5]; b.damp_ang = pr[6]; b.lift = pr[7]; b.am_lin = pr[8]; b.am_ang = pr[9];
-    const hydro::BodyOut o = hydro::solve_body(b, rho64, g64);
+    const hydro::BodyOut o = hydro::solve_body(b, rho64, g64, g_warp != 0);
     const float v[27] = {o.ratio, o.buoy_z, o.drag_fx, o.drag_fy, o.drag_fz, o.lift_fx, o.lift_fy, o.lift_fz,
                          o.drag_tx, o.drag_ty, o.drag_tz, o.am_fx, o.am_fy, o.am_fz, o.am_tx, o.am_ty, o.am_tz,
                          o.armb_x, o.armb_y, o.armb_z, o.armp_x, o.armp_y, o.armp_z,
