@@ -123,6 +123,10 @@ struct BodyOut {
 // not an fp32 number, and rounding it costs 4e-8 of the buoyancy before any arithmetic has happened.
 // `warp` (uniform over a launch) selects the semantics of the reference's Warp twin where it differs from
 // the Numba path (include/hydro.h HYDRO_SEM_WARP); the default is Numba.
+// ZERO_DRY = false leaves the outputs of a dry body unselected (whatever the arithmetic produced): for
+// callers that go straight to assemble_wrench, which zeroes the six results of a dry body itself - 6 selects
+// instead of ~30.
+template <bool ZERO_DRY = true>
 HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp = false)
 {
     const float rho = (float)rho64, g = (float)g64;
@@ -381,7 +385,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
 
     // ---- A4: dry bodies return zeros for every output (:277-279) ----
     // (selects, not multiplies: a dry body must give exact zeros whatever the rest evaluated to)
-#define HYDRO_LIVE(x) (wet ? (x) : 0.0f)
+#define HYDRO_LIVE(x) ((ZERO_DRY && !wet) ? 0.0f : (x))
     o.ratio = HYDRO_LIVE(ratio);
     o.buoy_z = HYDRO_LIVE(buoy_z);
     o.drag_fx = HYDRO_LIVE(lin_k * b.vx); o.drag_fy = HYDRO_LIVE(lin_k * b.vy); o.drag_fz = HYDRO_LIVE(lin_k * b.vz);
@@ -396,9 +400,10 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // N6: a dry body's centres are zeros in Numba (:277-279); the Warp twin reports cob (the position, or the
     // mean of whatever keypoints are wet) and cop = cob (warp_hydrodynamics.py:59-61,290) - component mode only,
     // every force is zero either way.
-    const bool arms = wet || warp;
+    const bool arms = wet || warp || !ZERO_DRY;
     o.armb_x = arms ? armb_x : 0.0f; o.armb_y = arms ? armb_y : 0.0f; o.armb_z = arms ? armb_z : 0.0f;
-    o.armp_x = wet ? armp_x : o.armb_x; o.armp_y = wet ? armp_y : o.armb_y; o.armp_z = wet ? armp_z : o.armb_z;
+    o.armp_x = (wet || !ZERO_DRY) ? armp_x : o.armb_x; o.armp_y = (wet || !ZERO_DRY) ? armp_y : o.armb_y;
+    o.armp_z = (wet || !ZERO_DRY) ? armp_z : o.armb_z;
     const float ks = lin_k * speed;                                 // drag_force = ks * v_hat
     o.dragarm_tx = HYDRO_LIVE(ks * pxv_x); o.dragarm_ty = HYDRO_LIVE(ks * pxv_y); o.dragarm_tz = HYDRO_LIVE(ks * pxv_z);
 #undef HYDRO_LIVE
@@ -419,9 +424,10 @@ HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass)
     const float tz = o.dragarm_tz + (o.armp_x * o.lift_fy - o.armp_y * o.lift_fx) + o.drag_tz + o.am_tz;
     const float f_mag = fast_sqrt(fx * fx + fy * fy + fz * fz);
     const float scale = fminf(1.0f, mass * kMaxAccel * fast_rcp(f_mag + kClampEps));
+    // A4: a dry body gets exact zeros (selects, not multiplies - whatever the rest evaluated to)
     Wrench w;
-    w.fx = fx * scale; w.fy = fy * scale; w.fz = fz * scale;
-    w.tx = tx * scale; w.ty = ty * scale; w.tz = tz * scale;
+    w.fx = o.wet ? fx * scale : 0.0f; w.fy = o.wet ? fy * scale : 0.0f; w.fz = o.wet ? fz * scale : 0.0f;
+    w.tx = o.wet ? tx * scale : 0.0f; w.ty = o.wet ? ty * scale : 0.0f; w.tz = o.wet ? tz * scale : 0.0f;
     w.scale = scale;
     return w;
 }

@@ -163,7 +163,7 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
     b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
     b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body(b, rho, g, warp);
+    const hydro::BodyOut o = hydro::solve_body<false>(b, rho, g, warp);
     return hydro::assemble_wrench(o, mass);
 }
 
@@ -182,10 +182,10 @@ __device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_ST
     b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
     b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body(b, rho, g, warp);
+    const hydro::BodyOut o = hydro::solve_body<false>(b, rho, g, warp);
     const hydro::Wrench w = hydro::assemble_wrench(o, mass);
-    k_lin = o.lin_k * w.scale;
-    k_ang = o.ang_k * w.scale;
+    k_lin = o.wet ? o.lin_k * w.scale : 0.0f;
+    k_ang = o.wet ? o.ang_k * w.scale : 0.0f;
     return w;
 }
 

@@ -20,11 +20,11 @@ extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, con
         b.bx = (b.wx - pv[3]) * inv_dt; b.by = (b.wy - pv[4]) * inv_dt; b.bz = (b.wz - pv[5]) * inv_dt;
         b.dimx = pr[0]; b.dimy = pr[1]; b.dimz = pr[2]; b.cd_lin = pr[3]; b.cd_ang = pr[4];
         b.damp_lin = pr[5]; b.damp_ang = pr[6]; b.lift = pr[7]; b.am_lin = pr[8]; b.am_ang = pr[9];
-        const hydro::BodyOut o = hydro::solve_body(b, rho64, g64, g_warp != 0);
+        const hydro::BodyOut o = hydro::solve_body<false>(b, rho64, g64, g_warp != 0);     // as the wrench kernels do
         const hydro::Wrench w = hydro::assemble_wrench(o, pr[10]);
         net_f[3 * i] = w.fx; net_f[3 * i + 1] = w.fy; net_f[3 * i + 2] = w.fz;
         net_t[3 * i] = w.tx; net_t[3 * i + 1] = w.ty; net_t[3 * i + 2] = w.tz;
-        ratio[i] = o.ratio;
+        ratio[i] = o.wet ? o.ratio : 0.0f;
     }
     return 0;
 }
