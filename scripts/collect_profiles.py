@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Container side: turn gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into the committed summaries under
+profiles/ and refresh profiles/traffic.json.      python scripts/collect_profiles.py r01d"""
+import csv, glob, json, os, shutil, statistics, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(REPO, "profiles")
+KERNEL = "wrench_tiled_kernel"
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getsize)
+    if not hits:
+        raise SystemExit(f"missing {pattern}")
+    return hits[-1]
+
+
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_c5_kernel_stats.csv"))
+shutil.copy(one("stats/**/*domain_stats.csv"), os.path.join(dst, f"{tag}_c5_domain_stats.csv"))
+
+
+def pmc(sub, label):
+    """per-dispatch counter values of the wrench kernel -> profiles/<tag>_c5_pmc_<label>.csv; returns {counter: [values]}"""
+    rows = []
+    for path in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                if KERNEL in r["Kernel_Name"]:
+                    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0].replace(", ", ",")
+                    rows.append((int(r["Dispatch_Id"]), name, r["Counter_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    with open(os.path.join(dst, f"{tag}_c5_pmc_{label}.csv"), "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["dispatch_id", "kernel", "counter", "value"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], f"{r[3]:.6f}"])
+    out = {}
+    for _, _, c, v in rows:
+        out.setdefault(c, []).append(v)
+    return out
+
+
+fetch = pmc("fetch", "FETCH_SIZE")["FETCH_SIZE"]
+write = pmc("write", "WRITE_SIZE")["WRITE_SIZE"]
+sq = pmc("sq", "SQ")
+bench = json.load(open(os.path.join(src, "bench.json")))
+n = bench["config"]["bodies_per_gpu"]
+fetch_raw = statistics.median(fetch) * 1024.0          # FETCH_SIZE / WRITE_SIZE are in KB
+write_b = statistics.median(write) * 1024.0
+tiles = (n + 63) // 64
+expected_read = tiles * 64 * (11 * 4 + 6 * 4) + tiles * 1920          # state minus px,py + prev + fp16 parameter record
+# the timed region of the stats run = its last `steps` launches of the wrench kernel
+trace = one("stats/**/*kernel_trace.csv") if glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True) else None
+mean_us = None
+if trace:
+    d = []
+    with open(trace, newline="") as f:
+        for r in csv.DictReader(f):
+            if KERNEL in r["Kernel_Name"]:
+                d.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    d.sort()
+    steps = json.load(open(os.path.join(src, "bench_stats.json")))["steps"]
+    mean_us = statistics.mean(x[1] for x in d[-steps:]) / 1e3
+path = os.path.join(dst, "traffic.json")
+tr = json.load(open(path))
+tr["c5:tiled"] = {
+    "hbm_bytes_per_launch": 2.0 * fetch_raw + write_b,
+    "fetch_size_bytes_raw": fetch_raw, "fetch_size_bytes_corrected": 2.0 * fetch_raw, "write_size_bytes": write_b,
+    "expected_read_bytes": expected_read, "expected_write_bytes": tiles * 64 * 24, "algorithmic_bytes": n * 130,
+    "source": f"profiles/{tag}_c5_pmc_FETCH_SIZE.csv + {tag}_c5_pmc_WRITE_SIZE.csv (rocprofv3 --pmc, separate passes, "
+              f"scripts/profile_round.sh; FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section; 2 x FETCH vs the known read "
+              f"bytes of this access pattern: {100.0 * (2.0 * fetch_raw / expected_read - 1.0):+.2f}%)",
+    "note": "read side is 98 B/body, not 106: px and py are provably unused by the wrench; their two 256-B runs of every state tile are skipped",
+    "sq_per_launch_median": {k: statistics.median(v) for k, v in sorted(sq.items())},
+    "kernel_trace_timed_region_mean_us": mean_us,
+    "in_bench_event_us": {"unprofiled": bench["roofline"]["kernel_us"],
+                          "under_kernel_trace": json.load(open(os.path.join(src, "bench_stats.json")))["roofline"]["kernel_us"]},
+}
+json.dump(tr, open(path, "w"), indent=1)
+print(json.dumps(tr["c5:tiled"], indent=1))

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the round's evidence for bench.py's headline, into gpurun_out/prof_<tag>/.
+#   scripts/profile_round.sh r01d
+# 1. un-profiled default bench line; 2. rocprofv3 --kernel-trace --stats of the same command;
+# 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters) with kernel-trace only.
+# python3 is named directly after `--` (no env / bash -c hop: the profiler's preload initialises the GPU).
+set -o pipefail
+tag=${1:-r01x}
+out=gpurun_out/prof_$tag
+rm -rf "$out"; mkdir -p "$out"
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --cpu-seconds 0 --no-extras > "$out/bench_stats.json" 2> "$out/stats.err" || exit 1
+short="--steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 bench.py $short > "$out/bench_fetch.json" 2> "$out/fetch.err" || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 bench.py $short > "$out/bench_write.json" 2> "$out/write.err" || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/sq" -- python3 bench.py $short > "$out/bench_sq.json" 2> "$out/sq.err" || exit 1
+# keep the merge-back small: the per-dispatch traces of the stats run are large
+find "$out/stats" -name "*kernel_trace.csv" -size +20M -delete
+ls -R "$out" | head -40
