@@ -1,0 +1,67 @@
+"""Designed (not random) populations for the conditioning tests: the situations in which terms of the wrench
+cancel each other, which random scenes only hit by accident (about one body in 10^5 at 100x)."""
+import numpy as np
+
+from oracle import hydro_oracle as ho
+from silver2_isaacsim_amd import scenes
+
+RHO, G, DT = 1025.0, 9.81, float(np.float32(1.0 / 60.0))
+
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def terminal_rise(n=4096, seed=11, cancel=100.0):
+    """Fully submerged bodies rising at (1 +- 1/cancel) times the speed at which drag along z equals
+    buoyancy: F_z is a `cancel`-fold cancellation between the two largest terms of the wrench."""
+    rng = np.random.default_rng(seed)
+    dims = np.exp(rng.uniform(np.log(0.05), np.log(1.0), (n, 3)))
+    q = scenes.random_unit_quats(rng, n)
+    dims32, q32 = _f32(dims), _f32(q)
+    ext = scenes.vertical_extent(q32, dims32)
+    pz = -ext * rng.uniform(1.5, 10.0, n)
+    coeffs = np.array([1.2, 0.8, 300.0, 150.0, 1.0, 0.0, 0.0]) * np.exp(rng.uniform(np.log(0.5), np.log(2.0), (n, 7)))
+    mass = 0.5 * RHO * dims.prod(axis=1) * 100.0                     # clamp far away
+    params = _f32(np.concatenate([dims32, coeffs, mass[:, None]], axis=1))
+    direction = np.stack([rng.normal(0, 0.05, n), rng.normal(0, 0.05, n), np.ones(n)], axis=1)
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+
+    def fz_over_b(speed):
+        st = np.zeros((n, 13)); st[:, 2] = pz; st[:, 3:7] = q32; st[:, 7:10] = direction * speed[:, None]
+        c = ho.solve_components(st, np.zeros((n, 6)), params.astype(np.float64), RHO, G)
+        return -c["drag_force"][:, 2] / c["buoyancy_force"][:, 2]
+    lo, hi = np.full(n, 1e-3), np.full(n, 1e3)
+    for _ in range(60):                                                # drag_z / B is monotone in the speed
+        mid = np.sqrt(lo * hi)
+        below = fz_over_b(mid) < 1.0
+        lo, hi = np.where(below, mid, lo), np.where(below, hi, mid)
+    speed = np.sqrt(lo * hi) * (1.0 + rng.choice([-1.0, 1.0], n) / cancel)
+    state = np.zeros((n, 13)); state[:, 0:2] = rng.uniform(-50, 50, (n, 2)); state[:, 2] = pz; state[:, 3:7] = q32
+    state[:, 7:10] = direction * speed[:, None]
+    state[:, 10:13] = rng.normal(0, 0.3, (n, 3))
+    state = _f32(state)
+    prev = state[:, 7:13].copy()                                       # no acceleration: added mass stays out of it
+    return state, prev, params
+
+
+def near_upright_floaters(n=4096, seed=12, tilt_deg=0.5):
+    """Partially submerged boxes tilted by ~tilt_deg, at rest: the whole torque is the buoyancy lever arm, whose
+    horizontal components are ~tan(tilt) of its length."""
+    rng = np.random.default_rng(seed)
+    dims = np.stack([rng.uniform(0.5, 1.5, n), rng.uniform(0.5, 1.5, n), rng.uniform(1.0, 3.0, n)], axis=1)
+    axis = np.stack([rng.normal(size=n), rng.normal(size=n), np.zeros(n)], axis=1)
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    ang = np.deg2rad(tilt_deg) * rng.uniform(0.5, 1.5, n)
+    q = np.concatenate([axis * np.sin(ang / 2)[:, None], np.cos(ang / 2)[:, None]], axis=1)
+    dims32, q32 = _f32(dims), _f32(q)
+    ext = scenes.vertical_extent(q32, dims32)
+    pz = ext * rng.uniform(-0.6, 0.6, n)
+    coeffs = np.tile(np.array([1.2, 0.8, 300.0, 150.0, 1.0, 0.05, 0.02]), (n, 1))
+    mass = 0.5 * RHO * dims.prod(axis=1)
+    params = _f32(np.concatenate([dims32, coeffs, mass[:, None]], axis=1))
+    state = np.zeros((n, 13)); state[:, 0:2] = rng.uniform(-50, 50, (n, 2)); state[:, 2] = pz; state[:, 3:7] = q32
+    state[:, 7:13] = rng.normal(0, 1e-4, (n, 6))                      # essentially at rest
+    state = _f32(state)
+    keep = scenes.branch_margins(state, params) > 1e-4
+    return state[keep], state[keep, 7:13].copy(), params[keep]
