@@ -72,8 +72,8 @@ class SimHost(Protocol):
 class _Group:
     """All registered prims that share one host and one (water density, gravity) pair."""
 
-    def __init__(self, host: SimHost, rho: float, g: float):
-        self.host, self.rho, self.g = host, rho, g
+    def __init__(self, host: SimHost, rho: float, g: float, semantics: str = "numba"):
+        self.host, self.rho, self.g, self.semantics = host, rho, g, semantics
         self.members: list["HydrodynamicsBehavior"] = []
         self.pending: set[int] = set()
         self.view: BodyView | None = None
@@ -93,6 +93,7 @@ class _Group:
         rows = np.stack([m._param_row(masses[i]) for i, m in enumerate(self.members)], axis=0)
         self.engine = HydroEngine(len(paths), self.host.device, self.rho, self.g)
         self.engine.set_params(rows)
+        self.engine.set_semantics(self.semantics)
         n = len(paths)
         self.force = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
         self.torque = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
@@ -132,10 +133,10 @@ class EngineRegistry:
         self._groups: dict[tuple, _Group] = {}
 
     def register(self, b: "HydrodynamicsBehavior") -> _Group:
-        key = (id(b._host), float(b._rho), float(b._g))
+        key = (id(b._host), float(b._rho), float(b._g), b.SEMANTICS)
         grp = self._groups.get(key)
         if grp is None:
-            grp = self._groups[key] = _Group(b._host, b._rho, b._g)
+            grp = self._groups[key] = _Group(b._host, b._rho, b._g, b.SEMANTICS)
         grp.members.append(b)
         grp.dirty = True
         grp.pending.clear()
@@ -180,6 +181,10 @@ class HydrodynamicsBehavior:
 
     BEHAVIOR_NS = cfg.BEHAVIOR_NS
     VARIABLES_TO_EXPOSE = cfg.variables_to_expose()
+    # "numba": the documented model (numba_hydrodynamics.py).  "warp": follow warp_hydrodynamics.py - the
+    # calculator the reference script instantiates (hydrodynamics_behavior.py:155) - where the two differ
+    # (added-mass rotation; include/hydro.h HYDRO_SEM_WARP).  Override in the scripted subclass.
+    SEMANTICS = "numba"
 
     def __init__(self, prim=None, host: SimHost | None = None, batched: bool = True):
         if prim is not None:
@@ -267,6 +272,7 @@ class HydrodynamicsBehavior:
         self._mass = float(masses[0])
         self._engine = HydroEngine(1, self._device, self._rho, self._g)
         self._engine.set_params(self._param_row(self._mass)[None, :])
+        self._engine.set_semantics(self.SEMANTICS)
         self._hydro_calculator = self._engine
         self._force = torch.empty((1, 3), dtype=torch.float32, device=self._engine.device)
         self._torque = torch.empty((1, 3), dtype=torch.float32, device=self._engine.device)

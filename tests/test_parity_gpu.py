@@ -208,6 +208,11 @@ def test_error_statuses(native_built):
         eng.step_wrench(S[:, :128].contiguous(), 0.0)
     with pytest.raises(HydroError, match="HYDRO_E_ARG"):
         eng.set_tuning(3)
+    with pytest.raises(HydroError, match="HYDRO_E_ARG"):
+        eng.set_tuning(0, 0, -1, 9)
+    with pytest.raises(ValueError):
+        eng.set_semantics("cuda")
+    assert eng._lib.hydro_set_semantics(eng._h, 7) == -1 and b"semantics" in eng._lib.hydro_last_error(eng._h)
     assert isinstance(HydroError(-1, "x"), RuntimeError)            # the plugin's except clause catches it
     with pytest.raises(HydroError, match="HYDRO_E_DEVICE"):
         HydroEngine(16, "cuda:63")
@@ -381,6 +386,11 @@ def test_tiled_entry_same_bits_as_plain_soa(name, n, native_built):
             torch.cuda.synchronize()
             o = scenes.from_tiled(out.cpu().numpy(), n)
             assert np.array_equal(o[:, :3], f_ref) and np.array_equal(o[:, 3:], t_ref), (block, nt)
+    # the residency cap (a dynamic-LDS request, the kernel uses none) changes scheduling only
+    for waves in (2, 4, 5, 8):
+        eng.set_tuning(0, 0, -1, waves)
+        o = scenes.from_tiled(eng.step_wrench_tiled(S, n, dt, prev=tiled(pv)).cpu().numpy(), n)
+        assert np.array_equal(o[:, :3], f_ref) and np.array_equal(o[:, 3:], t_ref), waves
     # padding lanes of the last tile are never written
     eng.set_tuning(0, 0, -1)
     out = torch.full((eng.tiles(n), 6, 64), -5.0, device=DEV)

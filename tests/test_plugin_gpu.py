@@ -40,7 +40,7 @@ def build_scene(batched, config_path=None, seed=0):
     return world, host, prims, behaviors
 
 
-def oracle_wrench(world, prims, host, prev6, dt):
+def oracle_wrench(world, prims, host, prev6, dt, semantics="numba"):
     n = len(prims)
     g = lambda p, k: host.get_exposed_variable(p, cfg.full_attr_name(k))       # noqa: E731
     params = np.array([[g(p, "xDimension"), g(p, "yDimension"), g(p, "zDimension"), g(p, "linearDragCoefficient"),
@@ -49,7 +49,7 @@ def oracle_wrench(world, prims, host, prev6, dt):
                         g(p, "angularAddedMassCoefficient"), float(world.masses[i])] for i, p in enumerate(prims)], np.float32)
     pos = world.positions.cpu().numpy(); q = world.orientations.cpu().numpy(); vel = world.velocities.cpu().numpy()
     state = np.concatenate([pos, q[:, [1, 2, 3, 0]], vel], axis=1)
-    f, t, _ = ho.step_wrench(state, prev6, params, 1025.0, 9.81, dt)
+    f, t, _ = ho.step_wrench(state, prev6, params, 1025.0, 9.81, dt, semantics=semantics)
     return f, t, params
 
 
@@ -86,6 +86,33 @@ def test_lifecycle_and_wrench_parity(batched, native_built):
     for b in behaviors:
         b.on_destroy()
     assert not prims[0].has(cfg.full_attr_name("gravity"))
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_warp_semantics_subclass(batched, native_built, monkeypatch):
+    """SEMANTICS = "warp" on the scripted class: the plugin then follows the calculator the reference script
+    instantiates (hydrodynamics_behavior.py:155, warp_hydrodynamics.py:216-230) in its added-mass rotation."""
+    hb.REGISTRY.clear()
+    monkeypatch.setattr(hb.HydrodynamicsBehavior, "SEMANTICS", "warp")
+    world, host, prims, behaviors = build_scene(batched, seed=5)
+    for b in behaviors:
+        b.on_play()
+    dt = 1.0 / 60.0
+    prev = np.zeros((len(prims), 6), np.float32)
+    for step in range(2):                       # step 0: v_last = 0, i.e. large accelerations -> added mass matters
+        host.step(dt)
+        torch.cuda.synchronize()
+        got_f = np.stack([world.applied[p.path][0].cpu().numpy() for p in prims])
+        got_t = np.stack([world.applied[p.path][1].cpu().numpy() for p in prims])
+        f_w, t_w, params = oracle_wrench(world, prims, host, prev, dt, "warp")
+        f_n, t_n, _ = oracle_wrench(world, prims, host, prev, dt, "numba")
+        assert ho.wrench_error(got_f, got_t, f_w, t_w, params, 1025.0, 9.81).max() <= 1e-5
+        assert ho.wrench_error(got_f, got_t, f_n, t_n, params, 1025.0, 9.81).max() > 1e-3      # and it is a different model
+        prev = world.velocities.cpu().numpy().copy()
+        world.velocities += 0.01 * torch.randn_like(world.velocities)
+    for b in behaviors:
+        b.on_stop()
+    hb.REGISTRY.clear()
 
 
 def test_state_fetch_failure_skips_the_step(native_built):
