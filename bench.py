@@ -160,6 +160,27 @@ def timed_steps(replicas, steps: int, warmup: int, stream, world: int):
     return float(t.item()), float(ev0.elapsed_time(ev1))
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box hands a
+    share of its host to each job; running 128 OpenMP threads on a 16-CPU share only measures thrashing)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.999)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, (quota + period - 1) // period))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline_leg(sc, replica, budget_s: float):
     """The C oracle (oracle/hydro_oracle.c, a port of the reference's Numba path) timed on this
     box's host cores on a bounded sample of the same workload, and used as the checker of the
@@ -176,7 +197,7 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
         if time.perf_counter() - t0 >= budget_s:
             break
     single = m * reps / (time.perf_counter() - t0)
-    threads = c_oracle.max_threads()
+    threads = min(c_oracle.max_threads(), usable_cpus())
     c_oracle.wrench(st, pv, pr, sc.rho, sc.g, sc.dt, threads=threads)               # spin the pool up
     reps_mt, t0 = 0, time.perf_counter()
     while True:
@@ -195,7 +216,7 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
         "value": single, "unit": "body-steps/s", "cores": 1, "kind": "port",
         "sample": f"{m} bodies of the bench scene x {reps} passes, fp64 C port of the Numba path "
                   f"(oracle/hydro_oracle.c, gcc -O3 -ffast-math), 1 thread",
-        "all_core_value": multi, "all_cores": threads, "cpu_model": cpu_model,
+        "all_core_value": multi, "all_cores": threads, "hardware_threads": os.cpu_count(), "cpu_model": cpu_model,
         "gpu_vs_oracle_max_rel_err": float(err.max()), "gpu_vs_oracle_n_over_1e-5": int((err > 1e-5).sum()),
         "gpu_vs_oracle_checked": int(m),
     }
