@@ -1,5 +1,6 @@
 // DEV-ONLY: relative issue cost of VALU instruction classes on gfx950 (wave64), to price the kernel's mix.
-//   hipcc -O3 --offload-arch=gfx950 -o gpurun_out/ubench_valu scripts/ubench_valu.hip && gpurun_out/ubench_valu
+//   hipcc -O3 --offload-arch=gfx950 -o scripts/_variants/ubench_valu.bin scripts/ubench_valu.hip   (here; it travels with gpurun)
+//   scripts/_variants/ubench_valu.bin                                                           (on the GPU box)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
