@@ -100,10 +100,13 @@ class Replica:
             self.prev = torch.from_numpy(scenes.to_soa(sc.prev[idx])).to(dev)
             self.out = torch.empty((6, sc.n), dtype=torch.float32, device=dev)
         self.index = idx
+        self._prepared = None
 
     def step(self):
         if self.layout == "tiled":
-            self.engine.step_wrench_tiled(self.state, self.n, self.dt, out=self.out, prev=self.prev)
+            if self._prepared is None:                 # arguments validated once; bound to the stream current now
+                self._prepared = self.engine.prepare_step_wrench_tiled(self.state, self.n, self.dt, out=self.out, prev=self.prev)
+            self._prepared()
         else:
             self.engine.step_wrench(self.state, self.dt, out=self.out, prev=self.prev)
 

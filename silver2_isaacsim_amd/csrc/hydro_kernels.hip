@@ -907,6 +907,15 @@ int fail(hydro_engine* h, int code, const char* what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail((h), (code), #call, e_); \
     } while (0)
 
+// Make the engine's device current only when it is not already (hipGetDevice is a thread-local read; a step
+// call from a single-GPU host then skips the hipSetDevice round trip).
+inline hipError_t use_device(int device)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return hipSuccess;
+    return hipSetDevice(device);
+}
+
 inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
 
 bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -1020,7 +1029,7 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics;
     a.inv_dt = (float)(1.0 / (double)dt);
     a.n = n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec >= 2) launch_soa<2, WRITE_PREV>(h, a, s);
     else launch_soa<1, WRITE_PREV>(h, a, s);
@@ -1044,7 +1053,7 @@ int set_params(hydro_engine* h, int64_t n, const float* const params[], int on_d
     if (!h) return HYDRO_E_ARG;
     if (!params) return fail(h, HYDRO_E_ARG, "null pointer table");
     if (n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "n out of range (0 <= n <= capacity)");
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     int rc = copy_fields(h, h->params, h->stride, params, HYDRO_PARAM_FIELDS, n, on_device);
     if (rc) return rc;
     if (half && n > 0) {
@@ -1203,7 +1212,7 @@ int hydro_set_params_f16(hydro_t* h, int64_t n, const float* const params[HYDRO_
 int hydro_reset_prev_velocity(hydro_t* h)
 {
     if (!h) return HYDRO_E_ARG;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipMemsetAsync(h->prev_tiled, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
@@ -1215,7 +1224,7 @@ int hydro_get_prev_velocity(hydro_t* h, int64_t n, float* const prev[HYDRO_PREV_
 {
     if (!h) return HYDRO_E_ARG;
     if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     if (h->prev_current == hydro_engine::kPrevTiled && n > 0) {   // last written in tiled form: refresh the SoA copy
         float* rows[HYDRO_PREV_FIELDS];
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
@@ -1236,7 +1245,7 @@ int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO
 {
     if (!h) return HYDRO_E_ARG;
     if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     int rc = copy_fields(h, h->prev, h->stride, prev, HYDRO_PREV_FIELDS, n, on_device);
     if (rc) return rc;
     if (n > 0) {
@@ -1289,7 +1298,7 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = (uint32_t)wrench_tile_stride;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (own_prev && (rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
@@ -1335,7 +1344,7 @@ int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t 
     for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
     a.mass = h->params + 10 * h->stride;
     a.shift = 6; a.mask = 63u; a.g = h->g; a.dt = dt; a.n = (uint32_t)n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
@@ -1363,7 +1372,7 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     a.out = wrench; a.out_stride = wrench ? (uint32_t)wrench_tile_stride : 0;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
     fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = dt;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
@@ -1390,7 +1399,7 @@ int hydro_pack_state_aos(hydro_t* h, int64_t n, const float* positions, const fl
     PackArgs a;
     a.pos = positions; a.quat = orientations; a.vel = velocities; a.quat_xyzw = quat_xyzw ? 1 : 0;
     a.st = state; a.st_stride = (uint32_t)state_tile_stride; a.n = (uint32_t)n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipLaunchKernelGGL(pack_state_aos_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
@@ -1408,7 +1417,7 @@ int hydro_unpack_wrench_aos(hydro_t* h, int64_t n, const float* wrench, int64_t 
     if (n == 0) return HYDRO_OK;
     UnpackArgs a;
     a.w = wrench; a.w_stride = (uint32_t)wrench_tile_stride; a.force = forces; a.torque = torques; a.n = (uint32_t)n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipLaunchKernelGGL(unpack_wrench_aos_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
@@ -1423,7 +1432,7 @@ int hydro_repack(hydro_t* h, int64_t n, int fields, float* const soa[], float* t
     int rc = check_tiled(h, n, tiled, tile_stride, fields, "null tiled buffer");
     if (rc) return rc;
     if (n == 0) return HYDRO_OK;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     return repack(h, soa, fields, tiled, tile_stride, n, to_tiled != 0, static_cast<hipStream_t>(stream));
 }
 
@@ -1444,7 +1453,7 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     if (n > ((int64_t)1 << 26)) return fail(h, HYDRO_E_ARG, "array-of-structs entry handles at most 2^26 bodies per call");
     a.pv = h->prev_tiled; a.prm = h->params_tiled;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const int grid = grid_for(n, kBlock);
@@ -1474,7 +1483,7 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
     for (int f = 0; f < HYDRO_COMP_FIELDS; ++f) { if (!comps[f]) return fail(h, HYDRO_E_ARG, "null component field"); a.out[f] = comps[f]; }
     fill_params(h, a);
     a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n, kBlock);
     if (h->half_coeffs) hipLaunchKernelGGL(components_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
@@ -1488,7 +1497,7 @@ static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, doub
     for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
     a.mass = h->params + 10 * h->stride;
     a.partials = h->ke_partials; a.out = out_dev; a.rotational = rotational; a.n = n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int blocks = grid_for(n > 0 ? n : 1, kBlock);
     if (blocks > kKeBlocks) blocks = kKeBlocks;
@@ -1513,7 +1522,7 @@ int hydro_step_components_aos(hydro_t* h, int64_t n, const float* position, cons
     a.lin_acc = linear_accel; a.ang_acc = angular_accel; a.prm = h->params_tiled;
     for (int k = 0; k < 8; ++k) { if (!out[k]) return fail(h, HYDRO_E_ARG, "null output tensor"); a.out[k] = out[k]; }
     a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = (uint32_t)n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = grid_for(n, kBlock);
     if (h->half_coeffs) hipLaunchKernelGGL(components_aos_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
@@ -1566,7 +1575,7 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
     a.mass = h->params + 10 * h->stride;
     a.si_stride = a.w_stride = a.so_stride = 0; a.shift = 31; a.mask = 0xffffffffu;
     a.g = h->g; a.dt = dt; a.n = (uint32_t)n;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
@@ -1601,7 +1610,7 @@ int hydro_set_tuning(hydro_t* h, int bodies_per_lane, int block_threads, int non
 int hydro_sync(hydro_t* h)
 {
     if (!h) return HYDRO_E_ARG;
-    HYDRO_HIP(h, hipSetDevice(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }

@@ -195,6 +195,32 @@ def test_component_mode_matches_reference_outputs(name, native_built):
     assert np.all(c[dry] == 0.0)                  # Numba semantics: cob = cop = 0 when dry (N6)
 
 
+def test_prepared_step_is_the_same_launch(native_built):
+    """prepare_step_wrench_tiled: arguments validated once, the callable re-issues the launch (same bits),
+    follows the buffers' contents, and refuses to run on a closed engine."""
+    fx = load_golden("c2")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = 1000
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(fx["params"][:n])
+    S, P = tiled(fx["state"][:n]), tiled(fx["prev"][:n])
+    ref = eng.step_wrench_tiled(S, n, dt, prev=P).clone()
+    out = eng.alloc_tiled(6, n)
+    step = eng.prepare_step_wrench_tiled(S, n, dt, out=out, prev=P)
+    assert step() is out
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    S[:, 2, :] -= 0.25                                   # same buffers, new contents
+    step(); ref2 = eng.step_wrench_tiled(S, n, dt, prev=P)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref2) and not torch.equal(out, ref)
+    with pytest.raises(ValueError):
+        eng.prepare_step_wrench_tiled(S[:, :5], n, dt)   # wrong field count is caught at prepare time
+    eng.close()
+    with pytest.raises(HydroError, match="HYDRO_E_STATE"):
+        step()
+
+
 def test_error_statuses(native_built):
     fx = load_golden("c2")
     eng = HydroEngine(128, DEV)
