@@ -285,33 +285,27 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     if (!has_area) { armp_x = armb_x; armp_y = armb_y; armp_z = armb_z; }     // cop = cob (:115,140)
     // arm_p x v_hat without cancellation.  h_a * area_a = V/2 on every axis, so
     //     arm_p = -(V/2A) R a,   a = W u,   u = R^T v_hat,   W = diag(face of axis a opposes the flow and is wet)
-    // which is parallel to v_hat (no torque from drag) when all three opposing faces are wet, up
-    // to the non-orthogonality of R.  With c = (I - W) u = u - a and R R^T = (1+2e) I - e (R + R^T):
-    //     (R a) x v_hat  =  -e (R v_hat + u) x v_hat  -  (R c) x v_hat          (exact)
-    // Use the direct form when |a| <= |c| and the complement form otherwise: the vector that is
-    // rotated and crossed with v_hat is then at least 45 degrees away from it - no cancellation.
+    // which is parallel to v_hat (no torque from drag) when all three opposing faces are wet.  Take the cross
+    // product in the BODY frame, where that zero is structural:
+    //     a x u = ((w_y - w_z) u_y u_z, (w_z - w_x) u_z u_x, (w_x - w_y) u_x u_y)
+    // and carry the non-orthogonality of the reference's matrix exactly (R = (1+e) R^ - e I, N7):
+    //     (R a) x v_hat = R y + e (y - a x v_hat),      y = (a x u + e (a x v_hat)) / (1 + e)
+    // (an identity in e, checked to 1e-15 for |q| in [0.85, 1.1]).  Every product is between quantities of
+    // full relative accuracy (u comes from the fp64 island) - nothing cancels, for any W and any |q|.
     const bool cx = fax != 0.0f, cy = fay != 0.0f, cz = faz != 0.0f;
-    const float ux2 = ux * ux, uy2 = uy * uy, uz2 = uz * uz;
-    const float a2 = (cx ? ux2 : 0.0f) + (cy ? uy2 : 0.0f) + (cz ? uz2 : 0.0f);
-    const float c2 = (cx ? 0.0f : ux2) + (cy ? 0.0f : uy2) + (cz ? 0.0f : uz2);
-    const bool direct = a2 <= c2;
-    const float sxv = (cx == direct) ? ux : 0.0f;                   // direct: a, complement: c
-    const float syv = (cy == direct) ? uy : 0.0f;
-    const float szv = (cz == direct) ? uz : 0.0f;
-    const float rsx = r00 * sxv + r01 * syv + r02 * szv;            // R a  or  R c
-    const float rsy = r10 * sxv + r11 * syv + r12 * szv;
-    const float rsz = r20 * sxv + r21 * syv + r22 * szv;
-    const float rvx = r00 * dx + r01 * dy + r02 * dz;               // R v_hat
-    const float rvy = r10 * dx + r11 * dy + r12 * dz;
-    const float rvz = r20 * dx + r21 * dy + r22 * dz;
-    // complement: (R a) = -e (R v_hat + u) - R c + (1+2e) v_hat, and the v_hat part drops out of the cross product
-    const float wx_ = direct ? rsx : -(qe * (rvx + ux) + rsx);
-    const float wy_ = direct ? rsy : -(qe * (rvy + uy) + rsy);
-    const float wz_ = direct ? rsz : -(qe * (rvz + uz) + rsz);
+    const float pyz = uy * uz, pzx = uz * ux, pxy = ux * uy;
+    const float axu_x = (cy == cz) ? 0.0f : (cy ? pyz : -pyz);
+    const float axu_y = (cz == cx) ? 0.0f : (cz ? pzx : -pzx);
+    const float axu_z = (cx == cy) ? 0.0f : (cx ? pxy : -pxy);
+    const float aax = cx ? ux : 0.0f, aay = cy ? uy : 0.0f, aaz = cz ? uz : 0.0f;       // a = W u
+    const float avx = aay * dz - aaz * dy, avy = aaz * dx - aax * dz, avz = aax * dy - aay * dx;   // a x v_hat
+    const float inv1pe = fast_rcp(1.0f + qe);
+    const float y0 = (axu_x + qe * avx) * inv1pe, y1 = (axu_y + qe * avy) * inv1pe, y2_ = (axu_z + qe * avz) * inv1pe;
+    const float rax = (r00 * y0 + r01 * y1 + r02 * y2_) + qe * (y0 - avx);                // (R a) x v_hat
+    const float ray = (r10 * y0 + r11 * y1 + r12 * y2_) + qe * (y1 - avy);
+    const float raz = (r20 * y0 + r21 * y1 + r22 * y2_) + qe * (y2_ - avz);
     const float nhva = -0.5f * (b.dimx * b.dimy * b.dimz) * inv_area;              // -(V/2A)
-    float pxv_x = nhva * (wy_ * dz - wz_ * dy);                                    // arm_p x v_hat
-    float pxv_y = nhva * (wz_ * dx - wx_ * dz);
-    float pxv_z = nhva * (wx_ * dy - wy_ * dx);
+    float pxv_x = nhva * rax, pxv_y = nhva * ray, pxv_z = nhva * raz;              // arm_p x v_hat
     if (!has_area) {
         pxv_x = armb_y * dz - armb_z * dy; pxv_y = armb_z * dx - armb_x * dz; pxv_z = armb_x * dy - armb_y * dx;
     }
