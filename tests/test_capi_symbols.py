@@ -20,6 +20,14 @@ def test_header_declares_the_survey_minimum():
         assert need in names
 
 
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own (what a cgo / FFI binding would include)."""
+    import subprocess
+    r = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                        os.path.join(REPO, "include", "hydro.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_library_exports_every_declared_symbol(native_built):
     from silver2_isaacsim_amd import _native
     lib = _native.load()
@@ -44,6 +52,9 @@ def test_argument_errors_without_a_device(native_built):
     assert lib.hydro_sync(None) == -1
     assert lib.hydro_capacity(None) == 0
     assert lib.hydro_last_error(None) == b"null handle"
+    assert lib.hydro_set_scene(None, 1025.0, 9.81) == -1
+    assert lib.hydro_set_semantics(None, 0) == -1
+    assert lib.hydro_set_tuning(None, 0, 0, -1, -1) == -1
 
 
 def test_missing_library_fails_loudly(tmp_path):
