@@ -10,7 +10,8 @@ KERNEL = "wrench_tiled_kernel"
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getsize)
+    """newest match: gpurun merges a new run's files NEXT TO an older run's (different pid prefixes)"""
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit(f"missing {pattern}")
     return hits[-1]
@@ -24,7 +25,7 @@ shutil.copy(one("stats/**/*domain_stats.csv"), os.path.join(dst, f"{tag}_c5_doma
 def pmc(sub, label):
     """per-dispatch counter values of the wrench kernel -> profiles/<tag>_c5_pmc_<label>.csv; returns {counter: [values]}"""
     rows = []
-    for path in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for path in [one(os.path.join(sub, "**", "*counter_collection.csv"))]:
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
                 if KERNEL in r["Kernel_Name"]:
