@@ -142,15 +142,18 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
 
     // ---- row 2 and the vertical extent in fp64 (conditioning, see header) ----
     const double dqx = b.qx, dqy = b.qy, dqz = b.qz, dqw = b.qw;
-    const double d20 = 2.0 * (dqx * dqz - dqw * dqy);
-    const double d21 = 2.0 * (dqy * dqz + dqw * dqx);
-    const double d22 = 1.0 - 2.0 * (dqx * dqx + dqy * dqy);
+    // half of row 2 (t2a = R[2][a] / 2): the half-extent h_a = dim_a / 2 then needs no conversion of its own
+    // (e_a = h_a R[2][a] = dim_a t2a) and the factor 2 is applied to the fp32 copies, where it is exact
+    const double t20 = dqx * dqz - dqw * dqy;
+    const double t21 = dqy * dqz + dqw * dqx;
+    const double t22 = 0.5 - (dqx * dqx + dqy * dqy);
+    const double ddx = b.dimx, ddy = b.dimy, ddz = b.dimz;
     const float hx = 0.5f * b.dimx, hy = 0.5f * b.dimy, hz = 0.5f * b.dimz;
-    const double dex = (double)hx * d20, dey = (double)hy * d21, dez = (double)hz * d22;
+    const double dex = ddx * t20, dey = ddy * t21, dez = ddz * t22;
     const double extent = fabs(dex) + fabs(dey) + fabs(dez);
     const double zlo = (double)b.pz - extent;           // lowest keypoint  (z_min)
     const double zhi = (double)b.pz + extent;           // highest keypoint (z_max)
-    const float r20 = (float)d20, r21 = (float)d21, r22 = (float)d22;
+    const float r20 = 2.0f * (float)t20, r21 = 2.0f * (float)t21, r22 = 2.0f * (float)t22;
     const float ex = (float)dex, ey = (float)dey, ez = (float)dez;
     // The quaternion is used as given, never normalised (N7).  With e = |q|^2 - 1 the matrix above is
     // R = (1+e) R^ - e I for the true rotation R^, which gives the EXACT identities
@@ -179,7 +182,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // rounding g = 9.81 alone) are amplified by the cancellation ratio, so buoyancy, the z-drag and the
     // buoyancy torque are evaluated in fp64 from the raw inputs and rounded AFTER they have been summed
     // (below: fz_core, tbx, tby).  ~60 fp64 operations per body, hidden behind HBM on MI355X.
-    const double vol64 = ((double)b.dimx * (double)b.dimy) * (double)b.dimz;
+    const double vol64 = (ddx * ddy) * ddz;
     double ratio64 = (double)ratio + ((-zlo) - (double)ratio * (extent + extent)) * (double)fast_rcp(height);
     if (ratio >= 1.0f) ratio64 = 1.0;                   // clamped, degenerate height or fully in
     const double buoy64 = (rho64 * g64) * (ratio64 * vol64);
@@ -266,11 +269,12 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // s A = sum_a |(R^T v)_a| area_a with the un-normalised fp64 R^T v; |v| by one Newton step on sqrt.
     float fz_core;
     {
-        const double ddz = b.dimz, fxy = (double)b.dimx * (double)b.dimy;
-        const double sA64 = (cx_ ? fabs(urx) * ((double)b.dimy * ddz) : 0.0) + (cy_ ? fabs(ury) * ((double)b.dimx * ddz) : 0.0)
-                          + (cz_ ? fabs(urz) * fxy : 0.0);
+        const double sA64 = (cx_ ? fabs(urx) * (ddy * ddz) : 0.0) + (cy_ ? fabs(ury) * (ddx * ddz) : 0.0)
+                          + (cz_ ? fabs(urz) * (ddx * ddy) : 0.0);
+        // |v| = v2 r corrected by one Newton step on sqrt, r = 1/|v| from the fp32 path (0 at rest)
         const double v2_64 = dvx * dvx + dvy * dvy + dvz * dvz;
-        const double speed64 = (double)speed + (v2_64 - (double)speed * (double)speed) * (0.5 * (double)inv_speed);
+        const double rinv = inv_speed, s0 = v2_64 * rinv;
+        const double speed64 = s0 + (v2_64 - s0 * s0) * (0.5 * rinv);
         const double quad64 = moving ? (0.5 * rho64) * ((double)b.cd_lin * sA64) : 0.0;
         const double scale64 = (speed < kLowSpeed) ? speed64 * 5.0 : 1.0;
         const double link64 = (quad64 + (double)b.damp_lin * scale64) * ratio64;
@@ -329,8 +333,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     const float dcl = fminf(1.0f, fmaxf(-1.0f, d_raw));
     const float axx = dy * r22 - dz * r12, axy = dz * r02 - dx * r22, axz = dx * r12 - dy * r02;
     const float n_axis2 = axx * axx + axy * axy + axz * axz;
-    const float n_axis = fast_sqrt(n_axis2);
-    const bool lift_on = !(speed < kSpeedEps) && !(n_axis < kAxisEps);
+    const bool lift_on = !(speed < kSpeedEps) && !(n_axis2 < kAxisEps * kAxisEps);   // |axis| < 1e-6 (:210), no sqrt needed
     const float eta = 2.0f * qe * (1.0f - r22);
     const float clamp_on = (fabsf(d_raw) < 1.0f) ? 1.0f : 0.0f;    // |d| >= 1 -> asin(+-1): C_L = sin(+-pi) = 0
     const float c_l_over_n = 2.0f * dcl * clamp_on * fast_sqrt(fmaxf(0.0f, 1.0f - eta * fast_rcp(n_axis2)));
