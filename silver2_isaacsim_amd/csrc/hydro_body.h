@@ -282,14 +282,17 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     }
     const bool has_area = area > kAreaEps;
     const float inv_area = has_area ? fast_rcp(area) : 0.0f;
-    const float lpx = sx * hx * fax * inv_area, lpy = sy * hy * fay * inv_area, lpz = sz * hz * faz * inv_area;
+    // body-frame CoP arm: s_a h_a (|u_a| area_a) / A = -(V/2A) u_a on the axes that count (h_a area_a = V/2)
+    const float aax = cx_ ? ux : 0.0f, aay = cy_ ? uy : 0.0f, aaz = cz_ ? uz : 0.0f;     // a = W u
+    const float nhva = -0.5f * (b.dimx * b.dimy * b.dimz) * inv_area;                    // -(V/2A)
+    const float lpx = nhva * aax, lpy = nhva * aay, lpz = nhva * aaz;
     float armp_x = r00 * lpx + r01 * lpy + r02 * lpz;
     float armp_y = r10 * lpx + r11 * lpy + r12 * lpz;
     float armp_z = r20 * lpx + r21 * lpy + r22 * lpz;
     if (!has_area) { armp_x = armb_x; armp_y = armb_y; armp_z = armb_z; }     // cop = cob (:115,140)
     // arm_p x v_hat without cancellation.  h_a * area_a = V/2 on every axis, so
     //     arm_p = -(V/2A) R a,   a = W u,   u = R^T v_hat,   W = diag(face of axis a opposes the flow and is wet)
-    // which is parallel to v_hat (no torque from drag) when all three opposing faces are wet.  Take the cross
+    // (above), which is parallel to v_hat (no torque from drag) when all three opposing faces are wet.  Take the cross
     // product in the BODY frame, where that zero is structural:
     //     a x u = ((w_y - w_z) u_y u_z, (w_z - w_x) u_z u_x, (w_x - w_y) u_x u_y)
     // and carry the non-orthogonality of the reference's matrix exactly (R = (1+e) R^ - e I, N7):
@@ -301,14 +304,12 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     const float axu_x = (cy == cz) ? 0.0f : (cy ? pyz : -pyz);
     const float axu_y = (cz == cx) ? 0.0f : (cz ? pzx : -pzx);
     const float axu_z = (cx == cy) ? 0.0f : (cx ? pxy : -pxy);
-    const float aax = cx ? ux : 0.0f, aay = cy ? uy : 0.0f, aaz = cz ? uz : 0.0f;       // a = W u
     const float avx = aay * dz - aaz * dy, avy = aaz * dx - aax * dz, avz = aax * dy - aay * dx;   // a x v_hat
     const float inv1pe = fast_rcp(1.0f + qe);
     const float y0 = (axu_x + qe * avx) * inv1pe, y1 = (axu_y + qe * avy) * inv1pe, y2_ = (axu_z + qe * avz) * inv1pe;
     const float rax = (r00 * y0 + r01 * y1 + r02 * y2_) + qe * (y0 - avx);                // (R a) x v_hat
     const float ray = (r10 * y0 + r11 * y1 + r12 * y2_) + qe * (y1 - avy);
     const float raz = (r20 * y0 + r21 * y1 + r22 * y2_) + qe * (y2_ - avz);
-    const float nhva = -0.5f * (b.dimx * b.dimy * b.dimz) * inv_area;              // -(V/2A)
     float pxv_x = nhva * rax, pxv_y = nhva * ray, pxv_z = nhva * raz;              // arm_p x v_hat
     if (!has_area) {
         pxv_x = armb_y * dz - armb_z * dy; pxv_y = armb_z * dx - armb_x * dz; pxv_z = armb_x * dy - armb_y * dx;
