@@ -490,6 +490,7 @@ def main():
             guarded("closed_loop_c3_1024envs_implicit", closed_loop_rate, "c3", 19456, implicit_drag=True)
             guarded("closed_loop_c2_262144", closed_loop_rate, "c2", 262144, steps=1024)
             guarded("closed_loop_c2_262144_unfused", closed_loop_rate, "c2", 262144, steps=1024, fused=False)
+            guarded("closed_loop_c2_1048576", closed_loop_rate, "c2", 1048576, steps=512)
             out["extras"] = ex
         print(json.dumps(out), flush=True)
 

@@ -943,6 +943,12 @@ void fill_params(hydro_engine* h, Args& a)
 //   * 128-thread blocks: +8..12 % around 1M bodies (finer dispatch granularity shortens the ramp and
 //     the tail of a ~25 us launch), -3 % at 4M where 256 is kept.
 constexpr int64_t kNtMinBodies = 131072;
+// The fused step is the closed-loop kernel: ONE scene stepping on itself (state ping-pong + parameters,
+// ~150 B of working set per body).  Between ~0.45M and ~2.6M bodies that set fits, or mostly fits, the 256 MiB
+// Infinity Cache, and leaving the accesses temporal lets step k+1 find step k's output there: measured
+// (scripts/diag_mall.py, hipGraph x64) 16.5 vs 19.2 us at 0.5M, 28.9 vs 33.5 us at 1M, 41.0 vs 45.6 us at 1.5M,
+// 55.1 vs 58.5 us at 2M; below (L2-sized sets) and above (thrashing) non-temporal wins by 4-12 %.
+constexpr int64_t kFusedTemporalMin = 458752, kFusedTemporalMax = 2621440;
 constexpr int64_t kBigBlockMinBodies = 2097152;
 
 template <int BLOCK, int VEC, bool WRITE_PREV>
@@ -1374,7 +1380,7 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = dt;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
+    const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
 #define HYDRO_FUSED(HALF, NT) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true>), grid, blk, 0, s, fa); \
                                    else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false>), grid, blk, 0, s, fa); } while (0)
