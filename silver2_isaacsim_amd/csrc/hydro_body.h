@@ -267,7 +267,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     const float area = fax + fay + faz;                 // 0 at rest (u = 0): N1 completion
     // buoyancy + drag along z in fp64, rounded after the sum.  s A needs no division:
     // s A = sum_a |(R^T v)_a| area_a with the un-normalised fp64 R^T v; |v| by one Newton step on sqrt.
-    float fz_core;
+    float fz_core, lift_base;
     {
         const double sA64 = (cx_ ? fabs(urx) * (ddy * ddz) : 0.0) + (cy_ ? fabs(ury) * (ddx * ddz) : 0.0)
                           + (cz_ ? fabs(urz) * (ddx * ddy) : 0.0);
@@ -279,6 +279,9 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
         const double scale64 = (speed < kLowSpeed) ? speed64 * 5.0 : 1.0;
         const double link64 = (quad64 + (double)b.damp_lin * scale64) * ratio64;
         fz_core = (float)(buoy64 - link64 * dvz);
+        // 1/2 rho s^2 A ratio for the lift (:201), from the same fp64 pieces: the lift-arm torque routinely cancels
+        // the buoyancy / drag-arm torques 50-100x, and the fp32 chain of seven products was its weakest link (4e-7)
+        lift_base = (float)(((0.5 * rho64) * (speed64 * sA64)) * ratio64);
     }
     const bool has_area = area > kAreaEps;
     const float inv_area = has_area ? fast_rcp(area) : 0.0f;
@@ -339,7 +342,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     const float clamp_on = (fabsf(d_raw) < 1.0f) ? 1.0f : 0.0f;    // |d| >= 1 -> asin(+-1): C_L = sin(+-pi) = 0
     const float c_l_over_n = 2.0f * dcl * clamp_on * fast_sqrt(fmaxf(0.0f, 1.0f - eta * fast_rcp(n_axis2)));
     const float vhat2 = dx * dx + dy * dy + dz * dz;
-    const float lift_k = lift_on ? (half_rho * speed * speed * c_l_over_n * area * b.lift) * ratio : 0.0f;
+    const float lift_k = lift_on ? lift_base * (c_l_over_n * b.lift) : 0.0f;
 
     // ---- A10: added mass (:220-253; diagonal of numba_hydrodynamics_wrapper.py:101-112) ----
     const float rv = volume * rho;
