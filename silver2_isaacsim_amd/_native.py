@@ -80,7 +80,7 @@ def load(path: str | None = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("HYDRO_LIBRARY") or LIB_PATH     # HYDRO_LIBRARY: another build of libhydro.so (A/B runs)
     if not os.path.exists(p):
         raise OSError(f"{p} not found: the HIP extension is not built "
                       f"(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
