@@ -1,10 +1,14 @@
 // Per-body hydrodynamic wrench arithmetic for the gfx950 kernels.
 //
-// One call = one rigid body, one physics step.  fp32 throughout except the
-// vertical extent / submersion numerator, which is evaluated in fp64 because
-// `ratio = -z_min / (z_max - z_min)` cancels catastrophically for barely-wet
-// bodies (z_min = p_z - extent; SURVEY.md section 7 "hard parts").  No MFMA: the
-// path is elementwise per body.
+// One call = one rigid body, one physics step.  fp32, with an fp64 island (~120 of ~590 VALU
+// instructions) for the quantities whose fp32 rounding would be amplified by a cancellation:
+//   * the vertical extent / submersion numerator: `ratio = -z_min / (z_max - z_min)` cancels
+//     catastrophically for barely-wet bodies (z_min = p_z - extent; SURVEY.md section 7 "hard parts");
+//   * the body-frame flow direction R^T v (small components of edge-on faces);
+//   * buoyancy + drag along z, summed before rounding, and the buoyancy torque: the largest term of the
+//     wrench and the two that routinely cancel it (scene scalars rho, g arrive as doubles for the same reason);
+//   * |q|^2 - 1, which the reference carries into terms that would otherwise cancel exactly.
+// No MFMA: the path is elementwise per body.
 //
 // The model (what must come out) is the reference's
 //   numba_hydrodynamics.py:9-314      (A1-A11: rotation, submersion + CoB,
@@ -22,7 +26,8 @@
 //     the wrench only ever uses those differences (hydrodynamics_behavior.py:
 //     212-214) and forming world-space points first loses ~|p|*2^-24 in fp32;
 //   * at most one face per axis opposes the flow, selected by sign(R^T v_hat);
-//   * sin(2*asin(d)) = 2 d sqrt((1-d)(1+d));  (axis x v_hat) = up|v_hat|^2 + d v_hat.
+//   * sin(2*asin(d)) = 2 d sqrt((1-d)(1+d));  (axis x v_hat) = up|v_hat|^2 + d v_hat;
+//   * the CoP-arm drag torque is formed in the body frame, where its zero (all three faces wet) is structural.
 // N1 completion (speed <= 1e-6 -> area 0, CoP = CoB) as in oracle/hydro_oracle.py.
 //
 // This header is compiled for the device by hipcc and, for the CPU-side
