@@ -186,7 +186,8 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // drag torques against its lever-arm torque.  The fp32 roundings of the partners (1e-7 each, 4e-8 from
     // rounding g = 9.81 alone) are amplified by the cancellation ratio, so buoyancy, the z-drag and the
     // buoyancy torque are evaluated in fp64 from the raw inputs and rounded AFTER they have been summed
-    // (below: fz_core, tbx, tby).  ~60 fp64 operations per body, hidden behind HBM on MI355X.
+    // (below: fz_core, tbx, tby, lift_base).  ~80 more fp64 instructions per body; what they cost on MI355X is
+    // measured in DESIGN.md section 5 (nothing at 4M bodies or with fp32 coefficients, ~5 % in the 1M fp16 case).
     const double vol64 = (ddx * ddy) * ddz;
     double ratio64 = (double)ratio + ((-zlo) - (double)ratio * (extent + extent)) * (double)fast_rcp(height);
     if (ratio >= 1.0f) ratio64 = 1.0;                   // clamped, degenerate height or fully in
@@ -250,8 +251,8 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // In fp64 from the raw inputs: a face nearly edge-on to the flow has |u_a| << 1, and the fp32 dot
     // product R^T v_hat only delivers u_a to ~1e-7 ABSOLUTE (rounded R entries, rounded v_hat, rounded
     // sum).  When that face is the only wet one opposing the flow, the projected area, the CoP lever arm
-    // and the lift all inherit the relative error (7e-6 observed at |u_a| ~ 0.01).  18 fp64 operations;
-    // measured free on MI355X (the kernel is HBM-bound: 23.15 -> 23.18 us at 1M bodies).
+    // and the lift all inherit the relative error (7e-6 observed at |u_a| ~ 0.01).  18 fp64 operations
+    // (on their own measured free on MI355X: 23.15 -> 23.18 us at 1M bodies).
     // u = R^T v = v - 2 (w t - q x t),  t = q x v   (same polynomial in q as the matrix form, any |q|)
     const double dvx = b.vx, dvy = b.vy, dvz = b.vz;
     const double tx_ = dqy * dvz - dqz * dvy, ty_ = dqz * dvx - dqx * dvz, tz_ = dqx * dvy - dqy * dvx;
