@@ -241,10 +241,21 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     const float buoy_z = rho * (ratio * volume) * g;
 
     // ---- A6: speed and direction (:285-289) ----
-    const float speed = fast_sqrt(b.vx * b.vx + b.vy * b.vy + b.vz * b.vz);
-    const bool moving = speed > kSpeedEps;
-    const float inv_speed = moving ? fast_rcp(speed) : 0.0f;
-    const float dx = b.vx * inv_speed, dy = b.vy * inv_speed, dz = b.vz * inv_speed;   // v_hat (0 at rest)
+    // |v|, 1/|v| and v_hat correctly rounded from fp64 (Newton steps on the fp32 v_sqrt / v_rcp seeds): the speed
+    // enters the drag twice (1/2 rho s Cd A * s) and 1/|v| scales both v_hat and the body-frame direction u, so the
+    // 1-ulp errors of the device's sqrt and rcp (which the host instantiation does not have) showed up 3x in the
+    // tail of the GPU soak.  7 more fp64-class instructions.
+    const double dvx = b.vx, dvy = b.vy, dvz = b.vz;
+    const double v2_64 = dvx * dvx + dvy * dvy + dvz * dvz;
+    const float speed0 = fast_sqrt(b.vx * b.vx + b.vy * b.vy + b.vz * b.vz);
+    const bool moving = speed0 > kSpeedEps;
+    const double rinv = moving ? (double)fast_rcp(speed0) : 0.0;
+    const double s0 = v2_64 * rinv;
+    const double speed64 = s0 + (v2_64 - s0 * s0) * (0.5 * rinv);
+    const double inv64 = rinv * (2.0 - speed64 * rinv);
+    const float speed = (float)speed64;
+    const float inv_speed = (float)inv64;
+    const float dx = (float)(dvx * inv64), dy = (float)(dvy * inv64), dz = (float)(dvz * inv64);   // v_hat (0 at rest)
 
     // ---- A7: projected area + centre of pressure (:108-143) ----
     // u = R^T v_hat; face (axis a, sign s) has alignment -s*u_a and centre height p_z + s*e_a.
@@ -254,15 +265,12 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // and the lift all inherit the relative error (7e-6 observed at |u_a| ~ 0.01).  18 fp64 operations
     // (on their own measured free on MI355X: 23.15 -> 23.18 us at 1M bodies).
     // u = R^T v = v - 2 (w t - q x t),  t = q x v   (same polynomial in q as the matrix form, any |q|)
-    const double dvx = b.vx, dvy = b.vy, dvz = b.vz;
     const double tx_ = dqy * dvz - dqz * dvy, ty_ = dqz * dvx - dqx * dvz, tz_ = dqx * dvy - dqy * dvx;
     const double gx_ = (dqy * tz_ - dqz * ty_) - dqw * tx_;
     const double gy_ = (dqz * tx_ - dqx * tz_) - dqw * ty_;
     const double gz_ = (dqx * ty_ - dqy * tx_) - dqw * tz_;
     const double urx = dvx + 2.0 * gx_, ury = dvy + 2.0 * gy_, urz = dvz + 2.0 * gz_;      // R^T v
-    const float ux = (float)urx * inv_speed;
-    const float uy = (float)ury * inv_speed;
-    const float uz = (float)urz * inv_speed;
+    const float ux = (float)(urx * inv64), uy = (float)(ury * inv64), uz = (float)(urz * inv64);
     const float sx = (ux < 0.0f) ? 1.0f : -1.0f;        // sign of the face opposing the flow
     const float sy = (uy < 0.0f) ? 1.0f : -1.0f;
     const float sz = (uz < 0.0f) ? 1.0f : -1.0f;
@@ -272,15 +280,11 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     const bool cx_ = fax != 0.0f, cy_ = fay != 0.0f, cz_ = faz != 0.0f;
     const float area = fax + fay + faz;                 // 0 at rest (u = 0): N1 completion
     // buoyancy + drag along z in fp64, rounded after the sum.  s A needs no division:
-    // s A = sum_a |(R^T v)_a| area_a with the un-normalised fp64 R^T v; |v| by one Newton step on sqrt.
+    // s A = sum_a |(R^T v)_a| area_a with the un-normalised fp64 R^T v; |v| = speed64 from above.
     float fz_core, lift_base;
     {
         const double sA64 = (cx_ ? fabs(urx) * (ddy * ddz) : 0.0) + (cy_ ? fabs(ury) * (ddx * ddz) : 0.0)
                           + (cz_ ? fabs(urz) * (ddx * ddy) : 0.0);
-        // |v| = v2 r corrected by one Newton step on sqrt, r = 1/|v| from the fp32 path (0 at rest)
-        const double v2_64 = dvx * dvx + dvy * dvy + dvz * dvz;
-        const double rinv = inv_speed, s0 = v2_64 * rinv;
-        const double speed64 = s0 + (v2_64 - s0 * s0) * (0.5 * rinv);
         const double quad64 = moving ? (0.5 * rho64) * ((double)b.cd_lin * sA64) : 0.0;
         const double scale64 = (speed < kLowSpeed) ? speed64 * 5.0 : 1.0;
         const double link64 = (quad64 + (double)b.damp_lin * scale64) * ratio64;

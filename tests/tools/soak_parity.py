@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Parity soak: many seeded scenes through every fused entry point, EVERY body compared with the fp64 C
-oracle (OpenMP).  Writes profiles/r01_parity_soak.json.   python tests/tools/soak_parity.py [seeds] [n]"""
+oracle (OpenMP).  Writes gpurun_out/parity_soak.json.   python tests/tools/soak_parity.py [seeds] [n]
+HYDRO_SOAK_SEEDS=226,259 picks explicit seeds; HYDRO_LIBRARY=... another build of libhydro.so."""
 import json, os, sys, time
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
@@ -34,7 +35,8 @@ def run(sc, coeff, entry):
     return o
 
 t0 = time.time()
-for seed in range(100, 100 + seeds):
+seed_list = [int(x) for x in os.environ["HYDRO_SOAK_SEEDS"].split(",")] if os.environ.get("HYDRO_SOAK_SEEDS") else range(100, 100 + seeds)
+for seed in seed_list:
     for law, gated in (("c4", True), ("c4", False), ("c5", True), ("c5", False)):
         fn = scenes.scene_c4 if law == "c4" else scenes.scene_c5
         sc = fn(n=n, seed=seed, margin=1e-4 if gated else None)
