@@ -8,7 +8,8 @@
  *
  * Prints per-body wrench rows "Fx Fy Fz Tx Ty Tz" so that a test can compare them with the oracle.
  * It goes through the plain-SoA entry, then the tiled entry (repacked on device) and checks that the
- * two agree bit for bit, and exercises the error paths (status codes + hydro_last_error).
+ * two agree bit for bit, exercises the error paths (status codes + hydro_last_error), and runs a closed loop
+ * of 64 fused steps from a HIP graph captured on its own stream (same bits as the eager loop).
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -96,6 +97,57 @@ int main(int argc, char **argv)
     CHECK_HIP(hipStreamSynchronize(stream));
     CHECK_HIP(hipMemcpy(ke, d_ke, sizeof ke, hipMemcpyDeviceToHost));
     fprintf(stderr, "kinetic energy: %.9e + %.9e J\n", ke[0], ke[1]);
+
+    /* closed loop without a host round trip: 64 fused steps (wrench + integrator, ping-pong state buffers)
+     * captured ONCE into a HIP graph and replayed - the step functions neither allocate nor synchronise, so
+     * they are capture-safe.  The eager loop over the same 64 steps must give the same bits. */
+    {
+        enum { K = 64 };
+        float *a0, *a1, *b0, *b1;
+        const size_t sbytes = sizeof(float) * tiles * 13 * HYDRO_TILE;
+        CHECK_HIP(hipMalloc((void **)&a0, sbytes)); CHECK_HIP(hipMalloc((void **)&a1, sbytes));
+        CHECK_HIP(hipMalloc((void **)&b0, sbytes)); CHECK_HIP(hipMalloc((void **)&b1, sbytes));
+        CHECK_HIP(hipMemcpyAsync(a0, t_state, sbytes, hipMemcpyDeviceToDevice, stream));
+        CHECK_HIP(hipMemsetAsync(a1, 0, sbytes, stream));                       /* "previous" state: zero velocity */
+        CHECK_HIP(hipMemcpyAsync(b0, a0, sbytes, hipMemcpyDeviceToDevice, stream));
+        CHECK_HIP(hipMemcpyAsync(b1, a1, sbytes, hipMemcpyDeviceToDevice, stream));
+        const int64_t ss = 13 * HYDRO_TILE;
+        for (int k = 0; k < K; ++k) {                                           /* eager reference */
+            float *cur = (k & 1) ? a1 : a0, *old = (k & 1) ? a0 : a1;
+            CHECK_HYDRO(h, hydro_step_fused_tiled(h, n, cur, ss, old + 7 * HYDRO_TILE, ss, dt, old, ss, NULL, 0, 1, stream));
+        }
+        hipGraph_t graph; hipGraphExec_t exec;
+        CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < K; ++k) {
+            float *cur = (k & 1) ? b1 : b0, *old = (k & 1) ? b0 : b1;
+            CHECK_HYDRO(h, hydro_step_fused_tiled(h, n, cur, ss, old + 7 * HYDRO_TILE, ss, dt, old, ss, NULL, 0, 1, stream));
+        }
+        CHECK_HIP(hipStreamEndCapture(stream, &graph));
+        CHECK_HIP(hipGraphInstantiate(&exec, graph, NULL, NULL, 0));
+        CHECK_HIP(hipGraphLaunch(exec, stream));                                /* one host call = 64 physics steps */
+        CHECK_HIP(hipStreamSynchronize(stream));
+        float *ha = malloc(sbytes), *hb = malloc(sbytes);
+        CHECK_HIP(hipMemcpy(ha, a0, sbytes, hipMemcpyDeviceToHost));           /* K even: the newest state is in buffer 0 */
+        CHECK_HIP(hipMemcpy(hb, b0, sbytes, hipMemcpyDeviceToHost));
+        int same = 1, finite = 1;
+        for (int64_t i = 0; i < n; ++i)
+            for (int f = 0; f < 13; ++f) {
+                const size_t at = (size_t)(i / HYDRO_TILE) * 13 * HYDRO_TILE + (size_t)f * HYDRO_TILE + (size_t)(i % HYDRO_TILE);
+                if (memcmp(&ha[at], &hb[at], sizeof(float)) != 0) same = 0;
+                if (!(hb[at] == hb[at]) || hb[at] > 1e30f || hb[at] < -1e30f) finite = 0;
+            }
+        if (!same || !finite) { fprintf(stderr, "graph replay and eager loop disagree (same=%d finite=%d)\n", same, finite); return 6; }
+        hipEvent_t e0, e1; float ms = 0.0f;
+        CHECK_HIP(hipEventCreate(&e0)); CHECK_HIP(hipEventCreate(&e1));
+        CHECK_HIP(hipEventRecord(e0, stream));
+        for (int r = 0; r < 16; ++r) CHECK_HIP(hipGraphLaunch(exec, stream));
+        CHECK_HIP(hipEventRecord(e1, stream));
+        CHECK_HIP(hipEventSynchronize(e1));
+        CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        fprintf(stderr, "hip graph: %d fused steps per replay, bit-identical to the eager loop, %.2f us per physics step\n", K, ms * 1e3f / (16 * K));
+        CHECK_HIP(hipGraphExecDestroy(exec)); CHECK_HIP(hipGraphDestroy(graph));
+        free(ha); free(hb);
+    }
 
     for (int64_t i = 0; i < n; ++i)
         printf("%.9e %.9e %.9e %.9e %.9e %.9e\n", w[0 * n + i], w[1 * n + i], w[2 * n + i], w[3 * n + i], w[4 * n + i], w[5 * n + i]);
