@@ -87,8 +87,8 @@ def _stress_population(n=65536, seed=1):
 
 def _check_stress(f, t, state, prev, params, dt):
     """dims 1e-3..30 m, speeds and spins 1e-5..50, depths to 1e4 m, accelerations to 1e4: everything finite, the
-    bulk at fp32 resolution.  The tail is NOT gated at 1e-5 here: at 20-40 m/s the lift-arm torque (a chain of
-    ~10 fp32 products, 4e-7) can cancel the drag-arm torque 100x - about one body in 2e5 reaches 1.3e-5
+    bulk at fp32 resolution.  The tail is NOT gated at 1e-5 here: at 20-40 m/s the lift-arm torque can cancel
+    the drag-arm torque 80-100x with both good to 1.2-1.8e-7 - about one body in 3e5 reaches 1.1-1.9e-5
     (tests/tools/extreme_ranges.py prints the breakdown)."""
     assert np.isfinite(f).all() and np.isfinite(t).all()
     rf, rt, _ = ho.step_wrench(state, prev, params, pop.RHO, pop.G, dt)
