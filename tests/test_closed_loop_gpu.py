@@ -111,3 +111,17 @@ def test_config3_links_need_and_get_the_implicit_update(native_built):
     bad.close()
     with pytest.raises(ValueError):
         ClosedLoopSim(sc, fused=False, implicit_drag=True)
+
+
+def test_silver2_envs_example(native_built):
+    """examples/silver2_envs_headless.py: BASELINE config 3 (19 links x envs) in closed loop from a HIP graph."""
+    import importlib.util
+    import os
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("silver2_envs", os.path.join(REPO, "examples", "silver2_envs_headless.py"))
+    demo = importlib.util.module_from_spec(spec); spec.loader.exec_module(demo)
+    out = demo.main(["--envs", "256", "--steps", "512"])
+    assert out["bodies"] == 19 * 256 and out["finite"] and out["physics_steps"] == 512
+    assert out["rtf"] > 10.0                                            # 120 Hz scene, microseconds per step
+    ke0, ke1 = out["kinetic_energy_J"]["before"], out["kinetic_energy_J"]["after"]
+    assert ke1[1] < ke0[1]                                              # the angular drag dissipates the initial spin
