@@ -619,3 +619,36 @@ def test_config5_every_body_against_the_oracle(native_built):
     assert np.isfinite(f).all() and np.isfinite(t).all()
     assert np.percentile(err, 99.99) < 3e-6
     assert err.max() < 3e-5 and over <= 8
+
+
+@pytest.mark.parametrize("coeff", ["f32", "f16"])
+def test_host_pointer_tables_for_params_and_prev(coeff, native_built):
+    """on_device = 0: hydro_set_params_* / hydro_set_prev_velocity / hydro_get_prev_velocity take HOST arrays
+    (what a C or Kit host without device copies of its constants would pass) - same bits as the device path."""
+    import ctypes
+    from silver2_isaacsim_amd import _native as nat
+    fx = load_golden("c5")
+    n = 777
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    st, pv, pr = fx["state"][:n], fx["prev"][:n], fx["params"][:n]
+    ref = HydroEngine(n, DEV, rho, g)
+    ref.set_params(pr, coeff); ref.set_prev_velocity(pv)
+    S = tiled(st)
+    want = ref.step_wrench_tiled(S, n, dt).clone()                      # engine-owned previous velocity
+    want_prev = ref.get_prev_velocity().cpu().numpy()
+    eng = HydroEngine(n, DEV, rho, g)
+    lib = eng._lib
+    host_params = [np.ascontiguousarray(pr[:, f], np.float32) for f in range(nat.PARAM_FIELDS)]
+    host_prev = [np.ascontiguousarray(pv[:, f], np.float32) for f in range(nat.PREV_FIELDS)]
+    fn = lib.hydro_set_params_f16 if coeff == "f16" else lib.hydro_set_params_f32
+    assert fn(eng._h, n, nat.pointer_table([a.ctypes.data for a in host_params]), 0) == 0
+    assert lib.hydro_set_prev_velocity(eng._h, n, nat.pointer_table([a.ctypes.data for a in host_prev]), 0) == 0
+    eng.n, eng.coeff_dtype = n, coeff
+    got = eng.step_wrench_tiled(S, n, dt)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    back = [np.empty(n, np.float32) for _ in range(nat.PREV_FIELDS)]
+    assert lib.hydro_get_prev_velocity(eng._h, n, nat.pointer_table([a.ctypes.data for a in back]), 0) == 0
+    assert lib.hydro_sync(eng._h) == 0
+    assert np.array_equal(np.stack(back), want_prev) and np.array_equal(np.stack(back).T, st[:, 7:13])
+    ref.close(); eng.close()
