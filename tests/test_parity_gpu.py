@@ -242,6 +242,12 @@ def test_error_statuses(native_built):
     assert isinstance(HydroError(-1, "x"), RuntimeError)            # the plugin's except clause catches it
     with pytest.raises(HydroError, match="HYDRO_E_DEVICE"):
         HydroEngine(16, "cuda:63")
+    # small accessors
+    import ctypes
+    cnt = ctypes.c_int(-1)
+    assert eng._lib.hydro_device_count(ctypes.byref(cnt)) == 0 and cnt.value == torch.cuda.device_count()
+    assert eng._lib.hydro_stream(eng._h) and eng._lib.hydro_stream(None) is None      # the engine's private copy stream
+    assert eng._lib.hydro_capacity(eng._h) == 128
     # n == 0 is a no-op, not an error
     empty = torch.empty((13, 0), device=DEV)
     assert eng.step_wrench(empty, 1 / 60).shape == (6, 0)
