@@ -658,3 +658,37 @@ def test_host_pointer_tables_for_params_and_prev(coeff, native_built):
     assert lib.hydro_sync(eng._h) == 0
     assert np.array_equal(np.stack(back), want_prev) and np.array_equal(np.stack(back).T, st[:, 7:13])
     ref.close(); eng.close()
+
+
+def test_handles_are_independent_across_host_threads(native_built):
+    """not thread-safe per handle, safe across handles.  Four host threads, each with its own engine,
+    stream and buffers, step concurrently; every thread gets the bits of the single-threaded run."""
+    import threading
+    fx = load_golden("c4")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    n = 4096
+    st, pv, pr = fx["state"][:n], fx["prev"][:n], fx["params"][:n]
+    f_ref, t_ref = run_ext(st, pv, pr, rho, g, dt)
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(DEV)
+            eng = HydroEngine(n, DEV, rho, g)
+            eng.set_params(pr)
+            S, P = tiled(st), tiled(pv)
+            out = eng.alloc_tiled(6, n)
+            with torch.cuda.stream(stream):
+                for _ in range(300):
+                    eng.step_wrench_tiled(S, n, dt, out=out, prev=P, stream=stream)
+            stream.synchronize()
+            results[k] = scenes.from_tiled(out.cpu().numpy(), n)
+            eng.close()
+        except Exception as e:                     # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    for k in range(4):
+        assert np.array_equal(results[k][:, :3], f_ref) and np.array_equal(results[k][:, 3:], t_ref), k
