@@ -125,3 +125,26 @@ def test_silver2_envs_example(native_built):
     assert out["rtf"] > 10.0                                            # 120 Hz scene, microseconds per step
     ke0, ke1 = out["kinetic_energy_J"]["before"], out["kinetic_energy_J"]["after"]
     assert ke1[1] < ke0[1]                                              # the angular drag dissipates the initial spin
+
+
+def test_checkpoint_resume_is_bit_exact(native_built):
+    """SURVEY section 5 (checkpoint / resume): the only state of the path is the body state and the previous-step
+    velocity.  64 steps, snapshot to the host, a NEW engine resumed from the snapshot for 64 more steps == 128
+    uninterrupted steps, bit for bit."""
+    sc = scenes.scene_c2(n=2048, seed=21)
+    a = ClosedLoopSim(sc, fused=True)
+    a.run(128, graph_steps=64)
+    want = a.state()
+    b = ClosedLoopSim(sc, fused=True)
+    b.run(64, graph_steps=64)
+    cur = b.state()
+    b.synchronize()
+    old = scenes.from_tiled(b.old.cpu().numpy(), sc.n)              # the state one step earlier: its velocities are "prev"
+    a.close(); b.close()
+    snap = scenes.Scene(sc.name, cur.astype(np.float32), old[:, 7:13].astype(np.float32), sc.params, sc.rho, sc.g, sc.dt,
+                        sc.coeff_dtype, dict(sc.info))
+    c = ClosedLoopSim(snap, fused=True)
+    c.run(64, graph_steps=64)
+    got = c.state()
+    c.close()
+    assert np.array_equal(got, want)
