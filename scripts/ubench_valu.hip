@@ -22,6 +22,8 @@ template <int KIND> __global__ void __launch_bounds__(256) k(float* out, float s
             if constexpr (KIND == 5) { a[j] = (float)((double)a[j] * md); }                 // cvt + mul_f64 + cvt
             if constexpr (KIND == 6) a[j] = __builtin_amdgcn_rcpf(a[j]) + c;
             if constexpr (KIND == 7) a[j] = (a[j] > c) ? a[j] * m : c;                        // cmp + cndmask + mul
+            if constexpr (KIND == 8) { a[j] = __builtin_fmaf(a[j], m, c); d[j] = __builtin_fma(d[j], md, cd); }   // alternating fp32 / fp64
+            if constexpr (KIND == 9) { a[j] = __builtin_fmaf(a[j], m, c); p[j] = __builtin_elementwise_fma(p[j], mp, cp); }
         }
     }
     float s = 0; for (int j = 0; j < UNR; ++j) s += a[j] + (float)d[j] + p[j].x + p[j].y;
@@ -46,5 +48,6 @@ int main()
 {
     run<0>("v_fma_f32", 1); run<1>("v_fma_f64", 1); run<2>("v_pk_fma_f32", 1); run<3>("v_mul_f64", 1); run<4>("v_add_f64", 1);
     run<5>("cvt+mul_f64+cvt (3 instr)", 3); run<6>("v_rcp_f32 + add (2 instr)", 2); run<7>("cmp+cndmask+mul (3 instr)", 3);
+    run<8>("fma_f32 + fma_f64 alternating (2)", 2); run<9>("fma_f32 + pk_fma_f32 alternating (2)", 2);
     return 0;
 }
