@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define HYDRO_VERSION 0x000100
+/* 0.2.0: scene scalars are doubles (hydro_set_scene), hydro_set_semantics, waves_per_simd in hydro_set_tuning */
+#define HYDRO_VERSION 0x000200
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
