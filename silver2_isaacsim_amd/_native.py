@@ -84,6 +84,11 @@ def load(path: str | None = None) -> ctypes.CDLL:
     if not os.path.exists(p):
         raise OSError(f"{p} not found: the HIP extension is not built "
                       f"(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so, and whichever copy is mapped first serves
+    # every later user of that SONAME.  If libhydro.so came first it would bring the system runtime in, torch would
+    # then run on a runtime it was not built against, and device calls fail (hipGetDeviceCount -> HYDRO_E_DEVICE).
+    # The Python host uses torch for memory and streams anyway, so load it first.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(p)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

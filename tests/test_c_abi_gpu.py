@@ -44,3 +44,17 @@ def test_plain_c_host_program(tmp_path, native_built):
     ke_line = [l for l in run.stderr.splitlines() if l.startswith("kinetic energy")][0]
     lin = float(ke_line.split()[2])
     assert lin == pytest.approx(ho.kinetic_energy(fx["state"][:n], fx["params"][:n])[0], rel=1e-8)
+
+
+def test_library_before_torch_in_a_fresh_process(native_built):
+    """`__graft_entry__.build()` (which loads libhydro.so) followed by `smoke()` in ONE fresh process: the binding
+    must end up on the HIP runtime torch ships, whichever of the two is asked for first (two runtimes in one
+    process made hipGetDeviceCount fail -> HYDRO_E_DEVICE)."""
+    import sys
+    code = "import __graft_entry__ as g; g.build(); g.smoke()"
+    res = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "[smoke]" in res.stdout, res.stderr[-2000:]
+    code = ("from silver2_isaacsim_amd import _native as n; n.load(); import torch; "
+            "from silver2_isaacsim_amd.engine import HydroEngine; e = HydroEngine(16, 'cuda:0'); e.close(); print('ok')")
+    res = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
