@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 /* 0.2.0: scene scalars are doubles (hydro_set_scene), hydro_set_semantics, waves_per_simd in hydro_set_tuning */
-#define HYDRO_VERSION 0x000200
+#define HYDRO_VERSION 0x000300
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
@@ -112,12 +112,16 @@ int hydro_set_prev_velocity(hydro_t *h, int64_t n, const float *const prev[HYDRO
  * hydro_step_wrench_ext  previous velocity is the caller's (e.g. last step's velocity arrays
  *                        of a ping-pong integrator): pure 144 B (fp32) / 130 B (fp16
  *                        coefficients) per body-step, nothing written but the wrench.
+ * `dt` is a double, as the `delta_time` Python float the reference's callback receives
+ * (hydrodynamics_behavior.py:138,200-202).  The arithmetic is fp32 with fp64 cores; a body whose net
+ * force or torque cancels its terms more than 8x is re-evaluated in fp64 from the raw inputs
+ * (DESIGN.md section 4), which is why 1/dt must not be rounded on the way in.
  * `stream` is a hipStream_t; NULL is HIP's default (null) stream, as in any HIP API.  The
  * engine's private stream (used for its own copies) is available from hydro_stream(). */
-int hydro_step_wrench(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], float dt,
+int hydro_step_wrench(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], double dt,
                       float *const wrench[HYDRO_WRENCH_FIELDS], void *stream);
 int hydro_step_wrench_ext(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS],
-                          const float *const prev[HYDRO_PREV_FIELDS], float dt,
+                          const float *const prev[HYDRO_PREV_FIELDS], double dt,
                           float *const wrench[HYDRO_WRENCH_FIELDS], void *stream);
 
 /* The same fused step on the engine's NATIVE layout, tiled struct-of-arrays: a group of F fields
@@ -130,7 +134,7 @@ int hydro_step_wrench_ext(hydro_t *h, int64_t n, const float *const state[HYDRO_
  *   prev != NULL : caller-owned; for a ping-pong integrator pass the previous state buffer
  *                  + 7 * 64 with its tile stride (the six velocity fields of each state tile). */
 int hydro_step_wrench_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
-                            const float *prev, int64_t prev_tile_stride, float dt,
+                            const float *prev, int64_t prev_tile_stride, double dt,
                             float *wrench, int64_t wrench_tile_stride, void *stream);
 
 /* Edges of the tiled layout: simulator tensors -> tiled state and tiled
@@ -151,7 +155,7 @@ int hydro_repack(hydro_t *h, int64_t n, int fields, float *const soa[], float *t
  * torques (n,3).  All five tensors 16-byte aligned.  Transposition is staged through LDS.
  * Previous velocity lives in the engine, as for hydro_step_wrench. */
 int hydro_step_wrench_aos(hydro_t *h, int64_t n, const float *positions, const float *orientations, int quat_xyzw,
-                          const float *velocities, float dt, float *forces, float *torques, void *stream);
+                          const float *velocities, double dt, float *forces, float *torques, void *stream);
 
 /* Component mode = WarpHydrodynamicsWrapper.calculate_hydrodynamic_forces
  * (warp_hydrodynamics_wrapper.py:79-132) / NumbaHydrodynamicsWrapper.calculate_hydrodynamic_forces
@@ -183,11 +187,11 @@ int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_
 /* Explicit rigid-body step standing in for PhysX in closed-loop runs:
  * semi-implicit Euler with gravity and box inertia.  state_out may alias state_in. */
 int hydro_integrate(hydro_t *h, int64_t n, const float *const state_in[HYDRO_STATE_FIELDS],
-                    const float *const wrench[HYDRO_WRENCH_FIELDS], float dt,
+                    const float *const wrench[HYDRO_WRENCH_FIELDS], double dt,
                     float *const state_out[HYDRO_STATE_FIELDS], void *stream);
 
 int hydro_integrate_tiled(hydro_t *h, int64_t n, const float *state_in, int64_t in_tile_stride,
-                          const float *wrench, int64_t wrench_tile_stride, float dt,
+                          const float *wrench, int64_t wrench_tile_stride, double dt,
                           float *state_out, int64_t out_tile_stride, void *stream);
 
 /* Wrench + integrator fused into one pass over tiled buffers (closed-loop runs): the state is read
@@ -199,7 +203,7 @@ int hydro_integrate_tiled(hydro_t *h, int64_t n, const float *state_in, int64_t 
  * which is unconditionally stable where the explicit form needs |k| dt / m < 2 (light bodies with
  * strong damping, e.g. the SILVER2 links at 120 Hz). */
 int hydro_step_fused_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
-                           const float *prev, int64_t prev_tile_stride, float dt,
+                           const float *prev, int64_t prev_tile_stride, double dt,
                            float *state_out, int64_t out_tile_stride,
                            float *wrench, int64_t wrench_tile_stride, int implicit_drag, void *stream);
 

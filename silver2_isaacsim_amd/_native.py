@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhydro.so")
@@ -39,24 +39,24 @@ SIGNATURES = {
     "hydro_reset_prev_velocity": (c_int, [c_void_p]),
     "hydro_get_prev_velocity": (c_int, [c_void_p, c_int64, _FP, c_int]),
     "hydro_set_prev_velocity": (c_int, [c_void_p, c_int64, _FP, c_int]),
-    "hydro_step_wrench": (c_int, [c_void_p, c_int64, _FP, c_float, _FP, c_void_p]),
-    "hydro_step_wrench_ext": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
-    "hydro_step_wrench_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
+    "hydro_step_wrench": (c_int, [c_void_p, c_int64, _FP, c_double, _FP, c_void_p]),
+    "hydro_step_wrench_ext": (c_int, [c_void_p, c_int64, _FP, _FP, c_double, _FP, c_void_p]),
+    "hydro_step_wrench_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                         c_void_p, c_int64, c_void_p]),
-    "hydro_step_fused_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
+    "hydro_step_fused_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                        c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
-    "hydro_integrate_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float,
+    "hydro_integrate_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                       c_void_p, c_int64, c_void_p]),
     "hydro_pack_state_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "hydro_unpack_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "hydro_repack": (c_int, [c_void_p, c_int64, c_int, _FP, c_void_p, c_int64, c_int, c_void_p]),
-    "hydro_step_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float,
+    "hydro_step_wrench_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_double,
                                       c_void_p, c_void_p, c_void_p]),
     "hydro_step_components": (c_int, [c_void_p, c_int64, _FP, _FP, _FP, c_void_p, c_void_p]),
     "hydro_step_components_aos": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [_FP, c_void_p, c_void_p]),
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
     "hydro_kinetic_energy_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_float, _FP, c_void_p]),
+    "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_double, _FP, c_void_p]),
     "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "hydro_sync": (c_int, [c_void_p]),
     "hydro_stream": (c_void_p, [c_void_p]),

@@ -102,6 +102,8 @@ struct BodyIn {
     float wx, wy, wz;
     float ax, ay, az;               // linear acceleration
     float bx, by, bz;               // angular acceleration
+    float pvx, pvy, pvz;            // previous-step linear / angular velocity: read by wrench_fp64 only
+    float pwx, pwy, pwz;            //   (the fused entry points; component mode gets accelerations and leaves them unset)
     float dimx, dimy, dimz;
     float cd_lin, cd_ang, damp_lin, damp_ang, lift, am_lin, am_ang;
 };
@@ -120,6 +122,7 @@ struct BodyOut {
     float tbx, tby;                 // buoyancy torque (cob - p) x (0,0,B), evaluated in fp64 (0 when dry)
     float fz_core;                  // buoyancy + drag force along z, summed in fp64 (0 when dry)
     float lin_k, ang_k;             // drag_force = lin_k * v, drag_torque = ang_k * w   (both <= 0; 0 when dry)
+    uint32_t wetmask;               // 27 keypoint sign bits (bit 26 - (9 i + 3 j + k) set: lattice point (i,j,k) is below the surface)
     bool wet;
 };
 
@@ -212,6 +215,7 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
             wetmask = shift_in_sign(wetmask, zij[j] + ez);
         }
     }
+    o.wetmask = wetmask;
     const float cnt = (float)__builtin_popcount(wetmask);
     const float s_i = (float)(__builtin_popcount(wetmask & lattice_mask(0, 2)) - __builtin_popcount(wetmask & lattice_mask(0, 0)));
     const float s_j = (float)(__builtin_popcount(wetmask & lattice_mask(1, 2)) - __builtin_popcount(wetmask & lattice_mask(1, 0)));
@@ -225,10 +229,14 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     // buoyancy torque (cob - p) x (0,0,B) = (arm_y B, -arm_x B, 0): the HORIZONTAL lever arm times the largest
     // force.  For a near-upright body arm_x, arm_y are small components of the rotated lattice mean
     // (|arm| ~ h_z): the fp32 product R l only delivers them to ~1e-7 |arm| absolute (4e-6 relative
-    // observed).  Rotate in fp64 instead:  R l = l + 2 (w t + q x t),  t = q x l  (x, y components only).
+    // observed), and so does an fp64 rotation of the fp32-rounded l (8e-6 of the torque at 0.3 degrees of tilt,
+    // 1e-5 of the metric's floor for a body floating exactly upright).  So the lattice mean itself is formed in
+    // fp64 - l = dim_a (S_a / 2 cnt), 1/cnt by one Newton step on the fp32 reciprocal - and rotated in fp64:
+    //     R l = l + 2 (w t + q x t),  t = q x l     (x, y components only).
     float tbx, tby;
     {
-        const double l0 = lbx, l1 = lby, l2 = lbz;
+        const double r0 = (double)inv_cnt, half_inv_cnt = r0 * (1.0 - (0.5 * (double)cnt) * r0);   // 1 / (2 cnt)
+        const double l0 = ddx * ((double)s_i * half_inv_cnt), l1 = ddy * ((double)s_j * half_inv_cnt), l2 = ddz * ((double)s_k * half_inv_cnt);
         const double bt0 = dqy * l2 - dqz * l1, bt1 = dqz * l0 - dqx * l2, bt2 = dqx * l1 - dqy * l0;
         const double arm64x = l0 + 2.0 * (dqw * bt0 + (dqy * bt2 - dqz * bt1));
         const double arm64y = l1 + 2.0 * (dqw * bt1 + (dqz * bt0 - dqx * bt2));
@@ -421,25 +429,255 @@ HYDRO_FN BodyOut solve_body(const BodyIn& b, double rho64, double g64, bool warp
     return o;
 }
 
-struct Wrench { float fx, fy, fz, tx, ty, tz, scale; };   // scale = the clamp factor that was applied
+struct Wrench {
+    float fx, fy, fz, tx, ty, tz;
+    float scale;                    // the clamp factor that was applied
+    bool ill;                       // the sum cancels its terms by more than kCancelGate (assemble_wrench): re-evaluate in fp64
+};
+
+// A body whose net force or net torque is more than this many times smaller than the terms it is the sum of
+// (1-norms; see assemble_wrench) is re-evaluated in fp64 by wrench_fp64.  Every term of the fp32 evaluation
+// is good to 1-2.5e-7 of ITSELF, so up to the gate the sum is good to sqrt(3) * 8 * 2.5e-7 = 3.5e-6 of itself
+// and past it (4 bodies in 10 000 of the bench populations, one wavefront in ~50) fp32 terms cannot deliver
+// 1e-5: 70-350x cancellations were the only margin-gated bodies above 1e-5 in 1.38e9 evaluations of round 1.
+#ifndef HYDRO_CANCEL_GATE
+#define HYDRO_CANCEL_GATE 8.0f        // build-time knob for A/B measurements (scripts/ab_variants.py)
+#endif
+constexpr float kCancelGate = HYDRO_CANCEL_GATE;
+constexpr float kCancelFloor = 1e-3f;   // forces below 1e-3 rho g V (torques: x the longest edge) count as zero
 
 // A14-A15: lever-arm torques, sum, safety clamp (hydrodynamics_behavior.py:212-226).
-HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass)
+HYDRO_FN Wrench assemble_wrench(const BodyOut& o, float mass, float weight_scale = 0.0f, float lmax = 0.0f)
 {
     const float fx = (o.drag_fx + o.lift_fx) + o.am_fx;
     const float fy = (o.drag_fy + o.lift_fy) + o.am_fy;
     const float fz = o.fz_core + (o.lift_fz + o.am_fz);            // fz_core = buoyancy + drag_z, summed in fp64
     // tau = arm_b x (0,0,Fb) + arm_p x F_drag + arm_p x F_lift + tau_drag + tau_am
-    const float tx = o.tbx + (o.dragarm_tx + (o.armp_y * o.lift_fz - o.armp_z * o.lift_fy) + o.drag_tx + o.am_tx);
-    const float ty = o.tby + (o.dragarm_ty + (o.armp_z * o.lift_fx - o.armp_x * o.lift_fz) + o.drag_ty + o.am_ty);
-    const float tz = o.dragarm_tz + (o.armp_x * o.lift_fy - o.armp_y * o.lift_fx) + o.drag_tz + o.am_tz;
+    const float lax = o.armp_y * o.lift_fz - o.armp_z * o.lift_fy;
+    const float lay = o.armp_z * o.lift_fx - o.armp_x * o.lift_fz;
+    const float laz = o.armp_x * o.lift_fy - o.armp_y * o.lift_fx;
+    const float tx = o.tbx + (o.dragarm_tx + lax + o.drag_tx + o.am_tx);
+    const float ty = o.tby + (o.dragarm_ty + lay + o.drag_ty + o.am_ty);
+    const float tz = o.dragarm_tz + laz + o.drag_tz + o.am_tz;
     const float f_mag = fast_sqrt(fx * fx + fy * fy + fz * fz);
     const float scale = fminf(1.0f, mass * kMaxAccel * fast_rcp(f_mag + kClampEps));
+    // conditioning of the two sums: 1-norm of the terms against the 1-norm of the result (fz_core counts as ONE
+    // term: buoyancy and z-drag were summed in fp64).  weight_scale = 1e-3 rho g V is the size below which the
+    // parity metric and the physics treat a force as zero.
+    const float sum_f = (fabsf(o.drag_fx) + fabsf(o.drag_fy) + fabsf(o.fz_core))
+                      + (fabsf(o.lift_fx) + fabsf(o.lift_fy) + fabsf(o.lift_fz))
+                      + (fabsf(o.am_fx) + fabsf(o.am_fy) + fabsf(o.am_fz));
+    const float sum_t = (fabsf(o.tbx) + fabsf(o.tby)) + (fabsf(o.dragarm_tx) + fabsf(o.dragarm_ty) + fabsf(o.dragarm_tz))
+                      + (fabsf(lax) + fabsf(lay) + fabsf(laz)) + (fabsf(o.drag_tx) + fabsf(o.drag_ty) + fabsf(o.drag_tz))
+                      + (fabsf(o.am_tx) + fabsf(o.am_ty) + fabsf(o.am_tz));
+    const float net_f = fmaxf(fabsf(fx) + fabsf(fy) + fabsf(fz), weight_scale);
+    const float net_t = fmaxf(fabsf(tx) + fabsf(ty) + fabsf(tz), weight_scale * lmax);
     // A4: a dry body gets exact zeros (selects, not multiplies - whatever the rest evaluated to)
     Wrench w;
     w.fx = o.wet ? fx * scale : 0.0f; w.fy = o.wet ? fy * scale : 0.0f; w.fz = o.wet ? fz * scale : 0.0f;
     w.tx = o.wet ? tx * scale : 0.0f; w.ty = o.wet ? ty * scale : 0.0f; w.tz = o.wet ? tz * scale : 0.0f;
     w.scale = scale;
+    w.ill = o.wet && (sum_f > kCancelGate * net_f || sum_t > kCancelGate * net_t);
+    return w;
+}
+
+// fp64 reciprocal and square root for the fp64 re-evaluation: the fp32 hardware seeds (v_rcp_f32 / v_rsq_f32, 1 ulp)
+// and two Newton steps in fp64 (2^-23 -> 2^-46 -> below fp64 resolution) - 7 and 11 instructions where the
+// IEEE-exact sequences the compiler expands `/` and sqrt() to take ~15 and ~25.  Arguments are within fp32 range
+// wherever the result is used (guarded by the model's own 1e-6 thresholds); sqrt64 returns 0 below 1e-30.
+HYDRO_FN double rcp64(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = (double)__builtin_amdgcn_rcpf((float)x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+HYDRO_FN double sqrt64(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = (double)__builtin_amdgcn_rsqf((float)x), h = 0.5 * r;
+    double y = x * r;
+    y = __builtin_fma(__builtin_fma(-y, y, x), h, y);
+    y = __builtin_fma(__builtin_fma(-y, y, x), h, y);
+    return x > 1e-30 ? y : 0.0;
+#else
+    return x > 1e-30 ? sqrt(x) : 0.0;
+#endif
+}
+
+// The whole wrench of one body in fp64, from the raw inputs: A13 (finite-difference acceleration), A1-A10 and
+// A14-A15 as the reference's float64 Numba path evaluates them (numba_hydrodynamics.py:256-314,
+// hydrodynamics_behavior.py:196-226), results rounded to fp32 once.  Called for the bodies assemble_wrench flags
+// (a wavefront runs it when any of its lanes is flagged; each lane keeps the result only if ITS OWN flag is set,
+// so what a body gets never depends on its neighbours).  Not on the fast path: plain fp64 sqrt and divisions.
+// The 27 keypoint tests are taken from the fp32 pass (`wetmask`: they are comparisons of fp64-derived heights
+// against zero and agree unless a keypoint is within 1e-7 edge lengths of the surface); every other branch of the
+// model is re-decided here in fp64.
+HYDRO_FN Wrench wrench_fp64(const BodyIn& b, uint32_t wetmask, float mass, double rho, double g, double inv_dt, bool warp)
+{
+    // (thresholds as the reference's float64 literals: (double)0.2f is 1.5e-8 away from 0.2, and speed / 0.2 is arithmetic)
+    const double qx = b.qx, qy = b.qy, qz = b.qz, qw = b.qw;
+    const double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    const double xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
+    const double sx = qw * x2, sy = qw * y2, sz = qw * z2;
+    const double r00 = 1.0 - (yy + zz), r01 = xy - sz, r02 = xz + sy;           // A1 (:14-49), not normalised (N7)
+    const double r10 = xy + sz, r11 = 1.0 - (xx + zz), r12 = yz - sx;
+    const double r20 = xz - sy, r21 = yz + sx, r22 = 1.0 - (xx + yy);
+    const double dx = b.dimx, dy = b.dimy, dz = b.dimz;
+    const double hx = 0.5 * dx, hy = 0.5 * dy, hz = 0.5 * dz, vol = dx * dy * dz;
+    const double pz = b.pz;
+    // A3: extent, submersion ratio (:86-96)
+    const double ex = hx * r20, ey = hy * r21, ez = hz * r22;
+    const double extent = fabs(ex) + fabs(ey) + fabs(ez);
+    const double zlo = pz - extent, zhi = pz + extent;
+    const bool dry = zlo >= 0.0, full = zhi <= 0.0;
+    const double height = zhi - zlo;
+    double ratio = fmin(1.0, -zlo * rcp64(height));
+    if (height < 1e-6) ratio = 1.0;
+    if (full) ratio = 1.0;
+    if (dry) ratio = 0.0;
+    Wrench w;
+    w.fx = w.fy = w.fz = w.tx = w.ty = w.tz = 0.0f; w.scale = 1.0f; w.ill = false;
+    if (!(ratio > 1e-9)) return w;                                   // A4 (:277-279)
+    // centre of buoyancy as a body-frame lever arm: mean lattice index of the wet keypoints (:69-84,99-103)
+    const int cnt = __builtin_popcount(wetmask);
+    const int s_i = __builtin_popcount(wetmask & lattice_mask(0, 2)) - __builtin_popcount(wetmask & lattice_mask(0, 0));
+    const int s_j = __builtin_popcount(wetmask & lattice_mask(1, 2)) - __builtin_popcount(wetmask & lattice_mask(1, 0));
+    const int s_k = __builtin_popcount(wetmask & lattice_mask(2, 2)) - __builtin_popcount(wetmask & lattice_mask(2, 0));
+    const double inv_cnt = (!dry && !full && cnt > 0) ? rcp64((double)cnt) : 0.0;
+    const double lbx = hx * (double)s_i * inv_cnt, lby = hy * (double)s_j * inv_cnt, lbz = hz * (double)s_k * inv_cnt;
+    const double abx = r00 * lbx + r01 * lby + r02 * lbz;
+    const double aby = r10 * lbx + r11 * lby + r12 * lbz;
+    const double abz = r20 * lbx + r21 * lby + r22 * lbz;
+    const double buoy = rho * (ratio * vol) * g;                                // A5 (:282)
+    // A6 (:285-289)
+    const double vx = b.vx, vy = b.vy, vz = b.vz;
+    const double speed = sqrt64(vx * vx + vy * vy + vz * vz);
+    const bool moving = speed > 1e-6;
+    const double inv_speed = moving ? rcp64(speed) : 0.0;
+    const double hx_ = vx * inv_speed, hy_ = vy * inv_speed, hz_ = vz * inv_speed;           // v_hat (0 at rest)
+    // A7 (:108-143): u = R^T v_hat; the face of axis a that opposes the flow has sign s_a = -sign(u_a)
+    const double ux = r00 * hx_ + r10 * hy_ + r20 * hz_;
+    const double uy = r01 * hx_ + r11 * hy_ + r21 * hz_;
+    const double uz = r02 * hx_ + r12 * hy_ + r22 * hz_;
+    const double fsx = (ux < 0.0) ? 1.0 : -1.0, fsy = (uy < 0.0) ? 1.0 : -1.0, fsz = (uz < 0.0) ? 1.0 : -1.0;
+    const double fax = ((ux != 0.0) && (pz + fsx * ex < 0.0)) ? fabs(ux) * (dy * dz) : 0.0;
+    const double fay = ((uy != 0.0) && (pz + fsy * ey < 0.0)) ? fabs(uy) * (dx * dz) : 0.0;
+    const double faz = ((uz != 0.0) && (pz + fsz * ez < 0.0)) ? fabs(uz) * (dx * dy) : 0.0;
+    const double area = fax + fay + faz;                                        // 0 at rest: N1 completion
+    const bool has_area = area > 1e-6;
+    const double inv_area = has_area ? rcp64(area) : 0.0;
+    const double lpx = fsx * hx * fax * inv_area, lpy = fsy * hy * fay * inv_area, lpz = fsz * hz * faz * inv_area;
+    double apx = r00 * lpx + r01 * lpy + r02 * lpz;
+    double apy = r10 * lpx + r11 * lpy + r12 * lpz;
+    double apz = r20 * lpx + r21 * lpy + r22 * lpz;
+    if (!has_area) { apx = abx; apy = aby; apz = abz; }                         // cop = cob (:115,140)
+    // A8 (:146-182)
+    const double half_rho = 0.5 * rho;
+    const double lin_quad = moving ? half_rho * (speed * speed) * (double)b.cd_lin * area : 0.0;
+    const double lin_scale = (speed < 0.2) ? speed * 5.0 : 1.0;
+    const double damp_l = (double)b.damp_lin * lin_scale;
+    const double fdx = -(lin_quad * hx_ + damp_l * vx) * ratio;
+    const double fdy = -(lin_quad * hy_ + damp_l * vy) * ratio;
+    const double fdz = -(lin_quad * hz_ + damp_l * vz) * ratio;
+    const double ox = b.wx, oy = b.wy, oz = b.wz;
+    const double wspeed = sqrt64(ox * ox + oy * oy + oz * oz);
+    const bool spinning = wspeed > 1e-6;
+    const double ang_quad = spinning ? half_rho * wspeed * (double)b.cd_ang * vol : 0.0;    // (1/2 rho w^2 Cd V) / w
+    const double ang_scale = (wspeed < 0.2) ? wspeed * 5.0 : 1.0;
+    const double ang_k = -(ang_quad + (double)b.damp_ang * ang_scale) * ratio;
+    const double tdx = ang_k * ox, tdy = ang_k * oy, tdz = ang_k * oz;
+    // A9 (:185-217)
+    double flx = 0.0, fly = 0.0, flz = 0.0;
+    if (!(speed < 1e-6)) {
+        const double d = fmin(1.0, fmax(-1.0, -uz));                            // -up . v_hat, up = R[:,2]
+        const double c_l = 2.0 * d * sqrt64(fmax(0.0, (1.0 - d) * (1.0 + d)));    // sin(2 asin d)
+        const double lift = half_rho * (speed * speed) * c_l * area * (double)b.lift;
+        const double axx = hy_ * r22 - hz_ * r12, axy = hz_ * r02 - hx_ * r22, axz = hx_ * r12 - hy_ * r02;   // v_hat x up
+        const double n_axis = sqrt64(axx * axx + axy * axy + axz * axz);
+        if (!(n_axis < 1e-6)) {
+            const double k = lift * ratio * rcp64(n_axis);
+            flx = k * (axy * hz_ - axz * hy_); fly = k * (axz * hx_ - axx * hz_); flz = k * (axx * hy_ - axy * hx_);
+        }
+    }
+    // A13 + A10 (hydrodynamics_behavior.py:196-202; numba_hydrodynamics.py:220-253)
+    const double ax = (vx - (double)b.pvx) * inv_dt, ay = (vy - (double)b.pvy) * inv_dt, az = (vz - (double)b.pvz) * inv_dt;
+    const double bx = (ox - (double)b.pwx) * inv_dt, by = (oy - (double)b.pwy) * inv_dt, bz = (oz - (double)b.pwz) * inv_dt;
+    double alx, aly, alz, blx, bly, blz;                                        // accelerations in the "local" frame
+    if (warp) {                                                                 // N3: quat_rotate = R (warp_hydrodynamics.py:216-217)
+        alx = r00 * ax + r01 * ay + r02 * az; aly = r10 * ax + r11 * ay + r12 * az; alz = r20 * ax + r21 * ay + r22 * az;
+        blx = r00 * bx + r01 * by + r02 * bz; bly = r10 * bx + r11 * by + r12 * bz; blz = r20 * bx + r21 * by + r22 * bz;
+    } else {                                                                    // R^T (numba_hydrodynamics.py:229-230)
+        alx = r00 * ax + r10 * ay + r20 * az; aly = r01 * ax + r11 * ay + r21 * az; alz = r02 * ax + r12 * ay + r22 * az;
+        blx = r00 * bx + r10 * by + r20 * bz; bly = r01 * bx + r11 * by + r21 * bz; blz = r02 * bx + r12 * by + r22 * bz;
+    }
+    const double rv = vol * rho;
+    const double kf = -(rv * (double)b.am_lin) * ratio, kt = -(rv * (double)b.am_ang) * ratio;
+    const double glx = kf * alx, gly = kf * aly, glz = kf * alz;
+    const double tlx = kt * (dy * dy + dz * dz) * blx, tly = kt * (dx * dx + dz * dz) * bly, tlz = kt * (dx * dx + dy * dy) * blz;
+    const double fax_ = r00 * glx + r01 * gly + r02 * glz, fay_ = r10 * glx + r11 * gly + r12 * glz, faz_ = r20 * glx + r21 * gly + r22 * glz;
+    const double tax = r00 * tlx + r01 * tly + r02 * tlz, tay = r10 * tlx + r11 * tly + r12 * tlz, taz = r20 * tlx + r21 * tly + r22 * tlz;
+    // A14 (hydrodynamics_behavior.py:212-218)
+    const double gx = fdx + flx, gy = fdy + fly, gz = fdz + flz;                // drag + lift act at the centre of pressure
+    const double fx = gx + fax_, fy = gy + fay_, fz = buoy + (gz + faz_);
+    const double tx = aby * buoy + (apy * gz - apz * gy) + tdx + tax;
+    const double ty = -abx * buoy + (apz * gx - apx * gz) + tdy + tay;
+    const double tz = (apx * gy - apy * gx) + tdz + taz;
+    // A15 (:220-226)
+    const double scale = fmin(1.0, (double)mass * 500.0 * rcp64(sqrt64(fx * fx + fy * fy + fz * fz) + 1e-6));
+    w.fx = (float)(fx * scale); w.fy = (float)(fy * scale); w.fz = (float)(fz * scale);
+    w.tx = (float)(tx * scale); w.ty = (float)(ty * scale); w.tz = (float)(tz * scale);
+    w.scale = (float)scale;
+    return w;
+}
+
+// Issue priority of this wavefront over the others on its SIMD (device only).
+HYDRO_FN void raise_priority()
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HYDRO_NO_SETPRIO)
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
+// True when `x` holds in ANY lane of the wavefront (device); the host instantiation has one "lane".
+HYDRO_FN bool any_lane(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(x) != 0;
+#else
+    return x;
+#endif
+}
+
+// One body of the fused entry points (A13 is done by the caller in fp32 for the fast pass: b.ax..b.bz; the raw
+// previous velocity travels along for the fp64 pass).  k_lin / k_ang: clamped drag coefficients for the implicit
+// integrator (drag_force = k_lin v, drag_torque = k_ang w), from the fp32 pass in both cases.
+// `reload(mass)` hands the body's inputs over a second time for the fp64 pass.  The kernels RE-READ them from
+// memory there instead of keeping 29 input registers alive across the whole fp32 pass (that costs a wave per
+// SIMD: 128+ VGPRs); the pass runs for one wavefront in ~50, so the extra traffic is ~2 % of lines that are
+// still in L2.  The host instantiation just returns the struct it has.
+template <typename Reload>
+HYDRO_FN Wrench solve_wrench(const BodyIn& b, float mass, double rho, double g, double inv_dt, bool warp, Reload reload,
+                             float* k_lin = nullptr, float* k_ang = nullptr, float* sub_ratio = nullptr)
+{
+    const BodyOut o = solve_body<false>(b, rho, g, warp);
+    if (sub_ratio) *sub_ratio = o.wet ? o.ratio : 0.0f;
+    const float weight_scale = kCancelFloor * ((float)(rho * g) * (b.dimx * b.dimy * b.dimz));
+    Wrench w = assemble_wrench(o, mass, weight_scale, fmaxf(b.dimx, fmaxf(b.dimy, b.dimz)));
+    if (k_lin) *k_lin = o.wet ? o.lin_k * w.scale : 0.0f;
+    if (k_ang) *k_ang = o.wet ? o.ang_k * w.scale : 0.0f;
+    const uint32_t wetmask = o.wetmask;
+    if (__builtin_expect(any_lane(w.ill), 0)) {             // wave-uniform branch, cold
+        float mass2;
+        raise_priority();                                   // the flagged wavefronts are the tail of the launch
+        const BodyIn b2 = reload(mass2);
+        const Wrench r = wrench_fp64(b2, wetmask, mass2, rho, g, inv_dt, warp);
+        if (w.ill) { w.fx = r.fx; w.fy = r.fy; w.fz = r.fz; w.tx = r.tx; w.ty = r.ty; w.tz = r.tz; w.scale = r.scale; }
+    }
     return w;
 }
 

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <type_traits>
 
 #include "../../include/hydro.h"
 #include "hydro_body.h"
@@ -25,6 +26,16 @@
 namespace {
 
 constexpr int kBlock = 256;                // 4 waves of 64 lanes
+// Resident waves per SIMD the wrench kernels are compiled for (second argument of __launch_bounds__: on HIP that is
+// waves per SIMD).  The fp32 pass needs ~100 VGPRs, the rarely executed fp64 re-evaluation ~125-150; with the bound
+// at 4 (<= 128 VGPRs) whatever does not fit is spilled INSIDE the cold block (it is marked unlikely and laid out
+// after s_endpgm), never on the path every wave runs.
+#ifndef HYDRO_MIN_WAVES
+#define HYDRO_MIN_WAVES 4
+#endif
+#ifndef HYDRO_TILED_REREAD
+#define HYDRO_TILED_REREAD 0        // A/B knob: 1 = the tiled wrench kernel re-reads a flagged body's records instead of keeping them
+#endif
 constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
 
 // --------------------------------------------------------------------------
@@ -142,15 +153,15 @@ struct SoaArgs {
     const float* mass;
     float* out[HYDRO_WRENCH_FIELDS];
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
-    float inv_dt;
+    double inv_dt;                           // fp64: the fast pass rounds it, the fp64 re-evaluation does not
     int warp;                                // HYDRO_SEM_WARP (uniform)
     int64_t n;
 };
 
-// One body from already-loaded scalars.
-__device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
-                                                     const float (&d)[3], const float (&c)[7], float mass,
-                                                     double rho, double g, float inv_dt, bool warp)
+// One body from already-loaded scalars.  inv_dt arrives in fp64 (the fp64 re-evaluation of ill-conditioned bodies,
+// hydro_body.h wrench_fp64, takes the finite difference itself); the fast pass uses its fp32 rounding.
+__device__ __forceinline__ hydro::BodyIn make_body(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
+                                                   const float (&d)[3], const float (&c)[7], float inv_dt)
 {
     hydro::BodyIn b;
     b.px = s[0]; b.py = s[1]; b.pz = s[2];
@@ -160,33 +171,33 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
     // A13: finite-difference acceleration (hydrodynamics_behavior.py:200-202)
     b.ax = (s[7] - pv[0]) * inv_dt; b.ay = (s[8] - pv[1]) * inv_dt; b.az = (s[9] - pv[2]) * inv_dt;
     b.bx = (s[10] - pv[3]) * inv_dt; b.by = (s[11] - pv[4]) * inv_dt; b.bz = (s[12] - pv[5]) * inv_dt;
+    b.pvx = pv[0]; b.pvy = pv[1]; b.pvz = pv[2]; b.pwx = pv[3]; b.pwy = pv[4]; b.pwz = pv[5];
     b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
     b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body<false>(b, rho, g, warp);
-    return hydro::assemble_wrench(o, mass);
+    return b;
 }
 
-// Same, also handing back the (clamped) linear / angular drag coefficients for the implicit integrator.
-__device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
-                                                       const float (&d)[3], const float (&c)[7], float mass,
-                                                       double rho, double g, float inv_dt, bool warp, float& k_lin, float& k_ang)
+// The compiler must not satisfy the re-read of a body's record from the registers of the first read (the point of
+// re-reading is that those registers are free during the fp32 pass): an empty asm with a memory clobber makes the
+// second set of loads distinct from the first.
+__device__ __forceinline__ void forget_memory() { asm volatile("" ::: "memory"); }
+
+// `reload(s, pv, d, c, mass)` reads the body's inputs again (wave-uniformly rare: hydro_body.h solve_wrench).
+template <typename Reload>
+__device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
+                                                     const float (&d)[3], const float (&c)[7], float mass,
+                                                     double rho, double g, double inv_dt, bool warp, Reload reload,
+                                                     float* k_lin = nullptr, float* k_ang = nullptr)
 {
-    hydro::BodyIn b;
-    b.px = s[0]; b.py = s[1]; b.pz = s[2];
-    b.qx = s[3]; b.qy = s[4]; b.qz = s[5]; b.qw = s[6];
-    b.vx = s[7]; b.vy = s[8]; b.vz = s[9];
-    b.wx = s[10]; b.wy = s[11]; b.wz = s[12];
-    b.ax = (s[7] - pv[0]) * inv_dt; b.ay = (s[8] - pv[1]) * inv_dt; b.az = (s[9] - pv[2]) * inv_dt;
-    b.bx = (s[10] - pv[3]) * inv_dt; b.by = (s[11] - pv[4]) * inv_dt; b.bz = (s[12] - pv[5]) * inv_dt;
-    b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
-    b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
-    b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body<false>(b, rho, g, warp);
-    const hydro::Wrench w = hydro::assemble_wrench(o, mass);
-    k_lin = o.wet ? o.lin_k * w.scale : 0.0f;
-    k_ang = o.wet ? o.ang_k * w.scale : 0.0f;
-    return w;
+    const float inv_dt32 = (float)inv_dt;
+    return hydro::solve_wrench(make_body(s, pv, d, c, inv_dt32), mass, rho, g, inv_dt, warp,
+                               [&](float& m2) {
+                                   float s2[HYDRO_STATE_FIELDS], pv2[HYDRO_PREV_FIELDS], d2[3], c2[7];
+                                   forget_memory();
+                                   reload(s2, pv2, d2, c2, m2);
+                                   return make_body(s2, pv2, d2, c2, inv_dt32);
+                               }, k_lin, k_ang);
 }
 
 // --------------------------------------------------------------------------
@@ -195,7 +206,7 @@ __device__ __forceinline__ hydro::Wrench body_wrench_k(const float (&s)[HYDRO_ST
 // with fp16 coefficients) parameters in, 24 B wrench out (+24 B if WRITE_PREV).
 // --------------------------------------------------------------------------
 template <int BLOCK, int VEC, bool HALF, bool WRITE_PREV, bool NT>
-__global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
+__global__ void __launch_bounds__(BLOCK, VEC == 1 ? HYDRO_MIN_WAVES : 2) wrench_soa_kernel(const SoaArgs a)
 {
     // Precondition (host side, launch_soa): a.n is a multiple of VEC; the <= VEC-1 leftover
     // bodies go to a second launch of the VEC=1 instance.  32-bit element offsets: the field
@@ -227,7 +238,20 @@ __global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
         for (int f = 0; f < 3; ++f) d[f] = dm[f][j];
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = cf[f][j];
-        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, a.warp != 0);
+        const uint32_t bj = base + j;
+        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, a.warp != 0,
+            [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
+                float t[1];
+#pragma unroll
+                for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { load_f32<1, false>(a.st[f], bj, t); s2[f] = t[0]; }
+#pragma unroll
+                for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) { load_f32<1, false>(a.pv[f], bj, t); p2[f] = t[0]; }
+#pragma unroll
+                for (int f = 0; f < 3; ++f) { load_f32<1, false>(a.dims[f], bj, t); d2[f] = t[0]; }
+#pragma unroll
+                for (int f = 0; f < 7; ++f) { load_coef<1, HALF, false>(a.coef[f], bj, t); c2[f] = t[0]; }
+                load_f32<1, false>(a.mass, bj, t); m2 = t[0];
+            });
         out[0][j] = w.fx; out[1][j] = w.fy; out[2][j] = w.fz;
         out[3][j] = w.tx; out[4][j] = w.ty; out[5][j] = w.tz;
     }
@@ -260,7 +284,7 @@ struct TiledArgs {
     const float* prm;                          // engine-owned: [tiles][11][64] f32, or f16 record (below)
     float* out;       uint32_t out_stride;     // 6 fields
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
-    float inv_dt;
+    double inv_dt;                           // fp64: the fast pass rounds it, the fp64 re-evaluation does not
     int warp;                                // HYDRO_SEM_WARP (uniform)
     uint32_t n;
 };
@@ -269,16 +293,13 @@ struct TiledArgs {
 constexpr uint32_t kPrmTileF32 = 11 * 64;
 constexpr uint32_t kPrmTileF16 = 480;
 
-template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT>
-__global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
+// state, previous velocity and parameter records of body (tile, lane): the ~28 loads of a wave are three
+// contiguous records, every field offset in the load instruction's immediate.
+template <bool HALF, bool NT>
+__device__ __forceinline__ void load_tile_records(const TiledArgs& a, uint32_t tile, uint32_t lane, uint32_t so, uint32_t po,
+                                                  float (&s)[HYDRO_STATE_FIELDS], float (&pv)[HYDRO_PREV_FIELDS],
+                                                  float (&d)[3], float (&c)[7], float& mass)
 {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t tile = i >> 6, lane = i & 63u;
-    // tile < 2^24 and strides < 2^24 (checked on the host): full-rate 24-bit multiplies
-    const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
-    const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
-    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
 #pragma unroll
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so, f * 256u));
 #pragma unroll
@@ -299,7 +320,30 @@ __global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
         for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
         mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
     }
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+}
+
+template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT>
+__global__ void __launch_bounds__(BLOCK, HYDRO_MIN_WAVES) wrench_tiled_kernel(const TiledArgs a)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    // tile < 2^24 and strides < 2^24 (checked on the host): full-rate 24-bit multiplies
+    const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
+    const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
+    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
+    load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+#if HYDRO_TILED_REREAD
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0,
+        [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
+            load_tile_records<HALF, false>(a, tile, lane, so, po, s2, p2, d2, c2, m2);
+        });
+#else
+    // this kernel keeps the inputs in registers for the fp64 pass: it fits 128 VGPRs (4 waves per SIMD) either way, and
+    // a re-read (an L2 / HBM round trip) makes the flagged wavefronts - whose length IS the tail of the launch - longer
+    const hydro::Wrench w = hydro::solve_wrench(make_body(s, pv, d, c, (float)a.inv_dt), mass, a.rho, a.g, a.inv_dt, a.warp != 0,
+                                                [&](float& m2) { m2 = mass; return make_body(s, pv, d, c, (float)a.inv_dt); });
+#endif
     const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
     stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
     stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
@@ -424,7 +468,7 @@ struct AosArgs {
     float* pv;              // engine-owned previous velocity, tiled [tiles][6][64] (read, then updated)
     const float* prm;       // engine-owned parameters, tiled record (f32 or fp16-coefficient form)
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
-    float inv_dt;
+    double inv_dt;                           // fp64: the fast pass rounds it, the fp64 re-evaluation does not
     int warp;                                // HYDRO_SEM_WARP (uniform)
     int64_t n;
 };
@@ -441,7 +485,7 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 template <bool HALF, bool NT>
-__global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
+__global__ void __launch_bounds__(kBlock, HYDRO_MIN_WAVES) wrench_aos_kernel(const AosArgs a)
 {
     constexpr int kWaves = kBlock / 64;
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves][64 * 9];   // per wave: 6*64 vel | 3*64 pos  (2.25 KiB)
@@ -472,34 +516,44 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
     const uint32_t lc = live ? lane : left - 1;                    // idle lanes of the last wave redo its last body
     const uint32_t ic = w0 + lc;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-    s[0] = lds_pos[3 * lc]; s[1] = lds_pos[3 * lc + 1]; s[2] = lds_pos[3 * lc + 2];
-    const f4 q = ldg<NT>(reinterpret_cast<const f4*>(a.quat) + ic);
-    if (a.quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
-    else             { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
-#pragma unroll
-    for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * lc + f];
     const uint32_t tile = ic >> 6, tl = ic & 63u;                  // w0 is a multiple of 64: tile == this wave's tile
     const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + tl) * 4u;
+    // one body's inputs: position and velocity from the wave's LDS slice, orientation as one float4, previous
+    // velocity and parameters from the engine's tiled records (also the re-read of the fp64 pass: the slice still
+    // holds the inputs then - forces and torques go into it only after the last read)
+    auto gather = [&](auto nt, float (&s_)[HYDRO_STATE_FIELDS], float (&pv_)[HYDRO_PREV_FIELDS], float (&d_)[3], float (&c_)[7], float& m_) {
+        constexpr bool kNt = decltype(nt)::value;
+        s_[0] = lds_pos[3 * lc]; s_[1] = lds_pos[3 * lc + 1]; s_[2] = lds_pos[3 * lc + 2];
+        const f4 q = ldg<kNt>(reinterpret_cast<const f4*>(a.quat) + ic);
+        if (a.quat_xyzw) { s_[3] = q.x; s_[4] = q.y; s_[5] = q.z; s_[6] = q.w; }
+        else             { s_[3] = q.y; s_[4] = q.z; s_[5] = q.w; s_[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
-    if constexpr (HALF) {
-        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + tl * 4u;
+        for (int f = 0; f < 6; ++f) s_[7 + f] = lds[6 * lc + f];
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
-        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + tl * 2u;
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv_[f] = ldg<kNt>(at<float>(a.pv, po, f * 256u));
+        if constexpr (HALF) {
+            const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + tl * 4u;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
-    } else {
-        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + tl * 4u;
+            for (int f = 0; f < 3; ++f) d_[f] = ldg<kNt>(at<float>(a.prm, qo, f * 256u));
+            m_ = ldg<kNt>(at<float>(a.prm, qo, 3 * 256u));
+            const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + tl * 2u;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
+            for (int f = 0; f < 7; ++f) c_[f] = half_bits_to_float(ldg<kNt>(at<unsigned short>(a.prm, ho, f * 128u)));
+        } else {
+            const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + tl * 4u;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
-    }
+            for (int f = 0; f < 3; ++f) d_[f] = ldg<kNt>(at<float>(a.prm, qo, f * 256u));
+#pragma unroll
+            for (int f = 0; f < 7; ++f) c_[f] = ldg<kNt>(at<float>(a.prm, qo + (3 + f) * 256u));
+            m_ = ldg<kNt>(at<float>(a.prm, qo, 10 * 256u));
+        }
+    };
+    gather(std::integral_constant<bool, NT>{}, s, pv, d, c, mass);
 
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0,
+        [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
+            gather(std::false_type{}, s2, p2, d2, c2, m2);
+        });
 
     if (live) {
 #pragma unroll
@@ -809,7 +863,7 @@ struct FusedArgs {
 };
 
 template <bool HALF, bool NT, bool IMPLICIT>
-__global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArgs fa)
+__global__ void __launch_bounds__(kBlock, HYDRO_MIN_WAVES) step_fused_tiled_kernel(const FusedArgs fa)
 {
     const TiledArgs& a = fa.t;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -818,30 +872,13 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArg
     const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
     const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-#pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so, f * 256u));
-#pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
-    if constexpr (HALF) {
-        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
-#pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
-        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
-#pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
-    } else {
-        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
-#pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
-#pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
-    }
+    load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
     float k_lin = 0.0f, k_ang = 0.0f;
-    hydro::Wrench w;
-    if constexpr (IMPLICIT) w = body_wrench_k(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0, k_lin, k_ang);
-    else w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+    // (the fp64 pass re-reads the records BEFORE anything is stored: state_out may alias the previous-velocity buffer)
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0,
+        [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
+            load_tile_records<HALF, false>(a, tile, lane, so, po, s2, p2, d2, c2, m2);
+        }, IMPLICIT ? &k_lin : nullptr, IMPLICIT ? &k_ang : nullptr);
     const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
     float o[HYDRO_STATE_FIELDS];
     integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, k_lin, k_ang, o);
@@ -1005,12 +1042,12 @@ void launch_soa(hydro_engine* h, const SoaArgs& a, hipStream_t s)
 
 template <bool WRITE_PREV>
 int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float* const prev[], float* const prev_out[],
-             float dt, float* const wrench[], void* stream)
+             double dt, float* const wrench[], void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
     if (!state || !wrench || !prev) return fail(h, HYDRO_E_ARG, "null pointer table");
-    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if (n == 0) return HYDRO_OK;
     SoaArgs a;
     int vec = h->vec ? h->vec : 1;
@@ -1033,7 +1070,7 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
     fill_params(h, a);
     a.mass = h->params + 10 * h->stride;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics;
-    a.inv_dt = (float)(1.0 / (double)dt);
+    a.inv_dt = 1.0 / dt;
     a.n = n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1264,7 +1301,7 @@ int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO
     return HYDRO_OK;
 }
 
-int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], float dt,
+int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], double dt,
                       float* const wrench[HYDRO_WRENCH_FIELDS], void* stream)
 {
     if (!h) return HYDRO_E_ARG;
@@ -1278,7 +1315,7 @@ int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STAT
 }
 
 int hydro_step_wrench_ext(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS],
-                          const float* const prev[HYDRO_PREV_FIELDS], float dt,
+                          const float* const prev[HYDRO_PREV_FIELDS], double dt,
                           float* const wrench[HYDRO_WRENCH_FIELDS], void* stream)
 {
     if (!h) return HYDRO_E_ARG;
@@ -1286,12 +1323,12 @@ int hydro_step_wrench_ext(hydro_t* h, int64_t n, const float* const state[HYDRO_
 }
 
 int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
-                            const float* prev, int64_t prev_tile_stride, float dt,
+                            const float* prev, int64_t prev_tile_stride, double dt,
                             float* wrench, int64_t wrench_tile_stride, void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
-    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if ((rc = check_tiled(h, n, state, state_tile_stride, HYDRO_STATE_FIELDS, "null state"))) return rc;
     if ((rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench"))) return rc;
     const bool own_prev = (prev == nullptr);
@@ -1303,7 +1340,7 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
     else { a.pv = prev; a.pv_stride = (uint32_t)prev_tile_stride; a.pv_out = nullptr; a.pvo_stride = 0; }
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = (uint32_t)wrench_tile_stride;
-    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (own_prev && (rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
@@ -1333,12 +1370,12 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
 }
 
 int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t in_tile_stride,
-                          const float* wrench, int64_t wrench_tile_stride, float dt,
+                          const float* wrench, int64_t wrench_tile_stride, double dt,
                           float* state_out, int64_t out_tile_stride, void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
-    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if ((rc = check_tiled(h, n, state_in, in_tile_stride, HYDRO_STATE_FIELDS, "null state_in"))) return rc;
     if ((rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench"))) return rc;
     if ((rc = check_tiled(h, n, state_out, out_tile_stride, HYDRO_STATE_FIELDS, "null state_out"))) return rc;
@@ -1349,7 +1386,7 @@ int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t 
     a.si_stride = (uint32_t)in_tile_stride; a.w_stride = (uint32_t)wrench_tile_stride; a.so_stride = (uint32_t)out_tile_stride;
     for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
     a.mass = h->params + 10 * h->stride;
-    a.shift = 6; a.mask = 63u; a.g = h->g; a.dt = dt; a.n = (uint32_t)n;
+    a.shift = 6; a.mask = 63u; a.g = h->g; a.dt = (float)dt; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
@@ -1357,13 +1394,13 @@ int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t 
 }
 
 int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
-                           const float* prev, int64_t prev_tile_stride, float dt,
+                           const float* prev, int64_t prev_tile_stride, double dt,
                            float* state_out, int64_t out_tile_stride,
                            float* wrench, int64_t wrench_tile_stride, int implicit_drag, void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
-    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if ((rc = check_tiled(h, n, state, state_tile_stride, HYDRO_STATE_FIELDS, "null state"))) return rc;
     if ((rc = check_tiled(h, n, prev, prev_tile_stride, HYDRO_PREV_FIELDS, "null prev (pass the previous state buffer + 7*64)"))) return rc;
     if ((rc = check_tiled(h, n, state_out, out_tile_stride, HYDRO_STATE_FIELDS, "null state_out"))) return rc;
@@ -1376,8 +1413,8 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     a.pv = prev; a.pv_stride = (uint32_t)prev_tile_stride; a.pv_out = nullptr; a.pvo_stride = 0;
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = wrench ? (uint32_t)wrench_tile_stride : 0;
-    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = (uint32_t)n;
-    fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = dt;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = (uint32_t)n;
+    fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = (float)dt;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
@@ -1443,13 +1480,13 @@ int hydro_repack(hydro_t* h, int64_t n, int fields, float* const soa[], float* t
 }
 
 int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,
-                          const float* velocities, float dt, float* forces, float* torques, void* stream)
+                          const float* velocities, double dt, float* forces, float* torques, void* stream)
 {
     const float* orientations_wxyz = orientations;
     int rc = check_common(h, n);
     if (rc) return rc;
     if (!positions || !orientations_wxyz || !velocities || !forces || !torques) return fail(h, HYDRO_E_ARG, "null tensor pointer");
-    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if (!aligned_to(positions, 16) || !aligned_to(orientations_wxyz, 16) || !aligned_to(velocities, 16) ||
         !aligned_to(forces, 16) || !aligned_to(torques, 16))
         return fail(h, HYDRO_E_ARG, "array-of-structs tensors must be 16-byte aligned");
@@ -1458,7 +1495,7 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     a.pos = positions; a.quat = orientations; a.quat_xyzw = quat_xyzw ? 1 : 0; a.vel = velocities; a.force = forces; a.torque = torques;
     if (n > ((int64_t)1 << 26)) return fail(h, HYDRO_E_ARG, "array-of-structs entry handles at most 2^26 bodies per call");
     a.pv = h->prev_tiled; a.prm = h->params_tiled;
-    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = (float)(1.0 / (double)dt); a.n = n;
+    a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
@@ -1563,13 +1600,13 @@ int hydro_kinetic_energy_tiled(hydro_t* h, int64_t n, const float* state, int64_
 }
 
 int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STATE_FIELDS],
-                    const float* const wrench[HYDRO_WRENCH_FIELDS], float dt,
+                    const float* const wrench[HYDRO_WRENCH_FIELDS], double dt,
                     float* const state_out[HYDRO_STATE_FIELDS], void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
     if (!state_in || !wrench || !state_out) return fail(h, HYDRO_E_ARG, "null pointer table");
-    if (!(dt > 0.0f)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
     if (n == 0) return HYDRO_OK;
     IntArgs a;
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) {
@@ -1580,7 +1617,7 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
     for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
     a.mass = h->params + 10 * h->stride;
     a.si_stride = a.w_stride = a.so_stride = 0; a.shift = 31; a.mask = 0xffffffffu;
-    a.g = h->g; a.dt = dt; a.n = (uint32_t)n;
+    a.g = h->g; a.dt = (float)dt; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);

@@ -216,7 +216,7 @@ class HydroEngine:
             p_ptr, p_stride = prev.data_ptr(), nat.PREV_FIELDS * nat.TILE
         fn = self._lib.hydro_step_wrench_tiled
         args = (self._h, ctypes.c_int64(n), ctypes.c_void_p(state.data_ptr()), ctypes.c_int64(nat.STATE_FIELDS * nat.TILE),
-                ctypes.c_void_p(p_ptr), ctypes.c_int64(p_stride), ctypes.c_float(float(dt)),
+                ctypes.c_void_p(p_ptr), ctypes.c_int64(p_stride), ctypes.c_double(float(dt)),
                 ctypes.c_void_p(out.data_ptr()), ctypes.c_int64(nat.WRENCH_FIELDS * nat.TILE), self._stream(stream))
         keep = (state, prev, out)                       # the buffers must outlive the callable
         check = self._check

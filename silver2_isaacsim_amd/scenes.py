@@ -145,13 +145,17 @@ def _gated(rng, n, draw, margin, max_rounds=64):
     state, prev, params = draw(rng, n)
     resampled = 0
     if margin:
+        # margins of the whole population once (in chunks: the (N,27) keypoint table of a million
+        # bodies is 200 MB), afterwards only of the bodies that were redrawn
+        bad = np.concatenate([lo + np.nonzero(branch_margins(state[lo:lo + 131072], params[lo:lo + 131072]) < margin)[0]
+                              for lo in range(0, n, 131072)]) if n else np.empty(0, dtype=np.int64)
         for _ in range(max_rounds):
-            bad = np.nonzero(branch_margins(state, params) < margin)[0]
             if bad.size == 0:
                 break
             resampled += int(bad.size)
             s2, p2, pa2 = draw(rng, bad.size, bad)
             state[bad], prev[bad], params[bad] = s2, p2, pa2
+            bad = bad[branch_margins(s2, pa2) < margin]
         else:
             raise RuntimeError("branch-margin resampling did not converge")
     return state, prev, params, resampled

@@ -65,3 +65,43 @@ def near_upright_floaters(n=4096, seed=12, tilt_deg=0.5):
     state = _f32(state)
     keep = scenes.branch_margins(state, params) > 1e-4
     return state[keep], state[keep, 7:13].copy(), params[keep]
+
+
+def torque_balance(n=4096, seed=15, cancel=300.0):
+    """Submerged and part-submerged bodies spinning at (1 +- 1/cancel) times the rate at which the angular drag
+    torque equals the sum of the other torque terms (buoyancy arm, drag arm, lift arm): the net torque is a
+    `cancel`-fold cancellation of terms that an fp32 evaluation delivers to 1-2e-7 each.  These are the bodies
+    that take the fp64 re-evaluation (hydro_body.h wrench_fp64)."""
+    rng = np.random.default_rng(seed)
+    dims = np.exp(rng.uniform(np.log(0.1), np.log(2.0), (n, 3)))
+    q = scenes.random_unit_quats(rng, n)
+    dims32, q32 = _f32(dims), _f32(q)
+    ext = scenes.vertical_extent(q32, dims32)
+    pz = np.where(rng.uniform(0, 1, n) < 0.5, ext * rng.uniform(-0.8, 0.8, n), -ext * rng.uniform(1.2, 5.0, n))
+    coeffs = np.array([1.2, 0.8, 300.0, 150.0, 1.0, 0.0, 0.0]) * np.exp(rng.uniform(np.log(0.5), np.log(2.0), (n, 7)))
+    mass = 0.5 * RHO * dims.prod(axis=1) * 100.0
+    params = _f32(np.concatenate([dims32, coeffs, mass[:, None]], axis=1))
+    v = _f32(rng.normal(0.0, 1.0, (n, 3)))
+    state = np.zeros((n, 13)); state[:, 0:2] = rng.uniform(-50, 50, (n, 2)); state[:, 2] = pz; state[:, 3:7] = q32
+    state[:, 7:10] = v
+    state = _f32(state)
+
+    def terms(w):
+        st = state.astype(np.float64); st[:, 10:13] = w
+        c = ho.solve_components(st, np.zeros((n, 6)), params.astype(np.float64), RHO, G)
+        p = st[:, 0:3]
+        rest = (np.cross(c["center_of_buoyancy"] - p, c["buoyancy_force"])
+                + np.cross(c["center_of_pressure"] - p, c["drag_force"] + c["lift_force"]))
+        return rest, c["drag_torque"]
+    rest, _ = terms(np.zeros((n, 3)))                                   # independent of the spin
+    rest_n = np.linalg.norm(rest, axis=1)
+    direction = rest / np.maximum(rest_n, 1e-300)[:, None]             # drag torque = ang_k w with ang_k < 0
+    lo, hi = np.full(n, 1e-6), np.full(n, 1e4)
+    for _ in range(70):                                                 # |drag torque| is monotone in the spin
+        mid = np.sqrt(lo * hi)
+        below = np.linalg.norm(terms(direction * mid[:, None])[1], axis=1) < rest_n
+        lo, hi = np.where(below, mid, lo), np.where(below, hi, mid)
+    spin = np.sqrt(lo * hi) * (1.0 + rng.choice([-1.0, 1.0], n) / cancel)
+    state[:, 10:13] = _f32(direction * spin[:, None])
+    keep = (scenes.branch_margins(state, params) > 1e-4) & (rest_n > 0) & (spin < 200.0)
+    return state[keep], state[keep, 7:13].copy(), params[keep]

@@ -5,7 +5,9 @@
   repo started the round with: max 2.2e-5 / 2.5e-5, 8 / 22 of 4 096 bodies over the gate; now max 1.7e-6.
 * near-upright floaters (the buoy scenes): at rest the whole torque is the horizontal buoyancy lever arm, 1 %
   (0.1 %) of its length at 0.5 (0.05) degrees of tilt.  Benign for both forms (3.9e-7 -> 1.9e-7): the wet lattice
-  is symmetric, so the arm is a single product; kept as the physical sanity case of the buoyancy torque."""
+  is symmetric, so the arm is a single product; kept as the physical sanity case of the buoyancy torque.
+* torque balance: the angular drag torque cancels the lever-arm torques 300x / 3000x.  fp32 terms (1-2e-7 each) cannot
+  deliver 1e-5 of such a sum: these bodies are flagged by assemble_wrench and re-evaluated in fp64 (round 2)."""
 import ctypes
 import os
 
@@ -20,7 +22,9 @@ GATE = 1e-5
 CASES = [("terminal_rise_100x", lambda: pop.terminal_rise(cancel=100.0)),
          ("terminal_rise_300x", lambda: pop.terminal_rise(seed=13, cancel=300.0)),
          ("floaters_0.5deg", lambda: pop.near_upright_floaters()),
-         ("floaters_0.05deg", lambda: pop.near_upright_floaters(seed=14, tilt_deg=0.05))]
+         ("floaters_0.05deg", lambda: pop.near_upright_floaters(seed=14, tilt_deg=0.05)),
+         ("torque_balance_300x", lambda: pop.torque_balance()),
+         ("torque_balance_3000x", lambda: pop.torque_balance(seed=16, cancel=3000.0))]
 
 
 def _check(name, f, t, state, prev, params):
@@ -32,6 +36,12 @@ def _check(name, f, t, state, prev, params):
         cancel = b / np.maximum(np.abs(rf[:, 2] / aux["scale"]), 1e-300)
         assert np.median(cancel) > 50.0                               # the population is what it claims to be
         assert np.median(err) < 2e-6
+    elif name.startswith("torque"):
+        p = state[:, 0:3].astype(np.float64)
+        parts = (np.cross(aux["center_of_buoyancy"] - p, aux["buoyancy_force"]), aux["drag_torque"],
+                 np.cross(aux["center_of_pressure"] - p, aux["drag_force"] + aux["lift_force"]))
+        net = np.maximum(np.linalg.norm(rt / aux["scale"][:, None], axis=1), 1e-300)
+        assert np.median(sum(np.linalg.norm(x, axis=1) for x in parts) / net) > 100.0
     else:
         assert np.median(err) < 1e-6
     return err
@@ -47,7 +57,7 @@ def emul(native_built):
         f = np.empty((n, 3), np.float32); t = np.empty((n, 3), np.float32); r = np.empty(n, np.float32)
         st, pv, pr = (np.ascontiguousarray(x, np.float32) for x in (state, prev, params))
         assert lib.emul_wrench(ctypes.c_int64(n), st.ctypes.data_as(fp), pv.ctypes.data_as(fp), pr.ctypes.data_as(fp),
-                               ctypes.c_double(pop.RHO), ctypes.c_double(pop.G), ctypes.c_float(np.float32(1.0 / pop.DT)),
+                               ctypes.c_double(pop.RHO), ctypes.c_double(pop.G), ctypes.c_double(pop.DT),
                                f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp)) == 0
         return f, t
     return run
@@ -87,14 +97,14 @@ def _stress_population(n=65536, seed=1):
 
 def _check_stress(f, t, state, prev, params, dt):
     """dims 1e-3..30 m, speeds and spins 1e-5..50, depths to 1e4 m, accelerations to 1e4: everything finite, the
-    bulk at fp32 resolution.  The tail is NOT gated at 1e-5 here: at 20-40 m/s the lift-arm torque can cancel
-    the drag-arm torque 80-100x with both good to 1.2-1.8e-7 - about one body in 3e5 reaches 1.1-1.9e-5
-    (tests/tools/extreme_ranges.py prints the breakdown)."""
+    bulk at fp32 resolution, every body inside 1e-5.  (At 20-40 m/s the lift-arm torque can cancel the drag-arm
+    torque 80-100x with both good to 1.2-1.8e-7: round 1 had about one body in 3e5 at 1.1-1.9e-5 here; those
+    bodies now take the fp64 re-evaluation.  tests/tools/extreme_ranges.py prints the breakdown.)"""
     assert np.isfinite(f).all() and np.isfinite(t).all()
     rf, rt, _ = ho.step_wrench(state, prev, params, pop.RHO, pop.G, dt)
     err = ho.wrench_error(f, t, rf, rt, params, pop.RHO, pop.G)
     assert np.median(err) < 2e-7 and np.percentile(err, 99.99) < 5e-6
-    assert (err > GATE).sum() <= 3 and err.max() < 5e-5
+    assert (err > GATE).sum() == 0, f"max {err.max():.3e}"
 
 
 def test_stress_ranges_host_arithmetic(native_built):
@@ -104,7 +114,7 @@ def test_stress_ranges_host_arithmetic(native_built):
     n = len(state)
     f = np.empty((n, 3), np.float32); t = np.empty((n, 3), np.float32); r = np.empty(n, np.float32)
     assert lib.emul_wrench(ctypes.c_int64(n), state.ctypes.data_as(fp), prev.ctypes.data_as(fp), params.ctypes.data_as(fp),
-                           ctypes.c_double(pop.RHO), ctypes.c_double(pop.G), ctypes.c_float(np.float32(1.0 / dt)),
+                           ctypes.c_double(pop.RHO), ctypes.c_double(pop.G), ctypes.c_double(dt),
                            f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp)) == 0
     _check_stress(f, t, state, prev, params, dt)
 

@@ -23,9 +23,8 @@ def emul(native_built):
         pr = np.ascontiguousarray(params, np.float32)
         n = len(st)
         f = np.empty((n, 3), np.float32); t = np.empty((n, 3), np.float32); r = np.empty(n, np.float32)
-        inv_dt = np.float32(1.0 / float(dt))
         rc = lib.emul_wrench(ctypes.c_int64(n), st.ctypes.data_as(fp), pv.ctypes.data_as(fp), pr.ctypes.data_as(fp),
-                             ctypes.c_double(rho), ctypes.c_double(g), ctypes.c_float(inv_dt),
+                             ctypes.c_double(rho), ctypes.c_double(g), ctypes.c_double(float(dt)),
                              f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp))
         assert rc == 0
         return f, t, r

@@ -88,7 +88,7 @@ def emul(native_built):
         lib.emul_set_semantics(int(warp))
         try:
             rc = lib.emul_wrench(ctypes.c_int64(n), st.ctypes.data_as(fp), pv.ctypes.data_as(fp), pr.ctypes.data_as(fp),
-                                 ctypes.c_double(rho), ctypes.c_double(g), ctypes.c_float(np.float32(1.0 / float(dt))),
+                                 ctypes.c_double(rho), ctypes.c_double(g), ctypes.c_double(float(dt)),
                                  f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp))
         finally:
             lib.emul_set_semantics(0)

@@ -20,7 +20,7 @@ def emul(sc):
     pr = np.ascontiguousarray(sc.params, np.float32)
     f = np.empty((sc.n, 3), np.float32); t = np.empty((sc.n, 3), np.float32); r = np.empty(sc.n, np.float32)
     lib.emul_wrench(ctypes.c_int64(sc.n), st.ctypes.data_as(fp), pv.ctypes.data_as(fp), pr.ctypes.data_as(fp),
-                    ctypes.c_double(sc.rho), ctypes.c_double(sc.g), ctypes.c_float(np.float32(1.0 / sc.dt)),
+                    ctypes.c_double(sc.rho), ctypes.c_double(sc.g), ctypes.c_double(sc.dt),
                     f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp))
     return f, t, r
 

@@ -37,7 +37,7 @@ if __name__ == "__main__":
     lib = ctypes.CDLL(os.path.join(REPO, "tests", "host_emul", "libemul.so")); fp = ctypes.POINTER(ctypes.c_float)
     f = np.empty((m, 3), np.float32); t = np.empty((m, 3), np.float32); r = np.empty(m, np.float32)
     lib.emul_wrench(ctypes.c_int64(m), state.ctypes.data_as(fp), prev.ctypes.data_as(fp), params.ctypes.data_as(fp), ctypes.c_double(1025.0),
-                    ctypes.c_double(9.81), ctypes.c_float(np.float32(1 / dt)), f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp))
+                    ctypes.c_double(9.81), ctypes.c_double(dt), f.ctypes.data_as(fp), t.ctypes.data_as(fp), r.ctypes.data_as(fp))
     rf, rt = c_oracle.wrench(state, prev, params, 1025.0, 9.81, dt, threads=8)
     err = ho.wrench_error(f, t, rf, rt, params, 1025.0, 9.81)
     print("bodies", m, "finite", bool(np.isfinite(f).all() and np.isfinite(t).all()), "max", err.max(), "over 1e-5:", int((err > 1e-5).sum()),
@@ -47,9 +47,9 @@ if __name__ == "__main__":
               f"|F| {np.linalg.norm(rf[i]):.3g} dF {np.linalg.norm(f[i] - rf[i]):.3g} |T| {np.linalg.norm(rt[i]):.3g} dT {np.linalg.norm(t[i] - rt[i]):.3g}")
     # component breakdown of the worst body
     i = int(np.argmax(err))
-    out = np.zeros(27, np.float32)
+    out = np.zeros(30, np.float32)
     lib.emul_body(state[i].ctypes.data_as(fp), prev[i].ctypes.data_as(fp), params[i].ctypes.data_as(fp), ctypes.c_double(1025.0), ctypes.c_double(9.81),
-                  ctypes.c_float(np.float32(1 / dt)), out.ctypes.data_as(fp))
+                  ctypes.c_double(dt), out.ctypes.data_as(fp))
     acc = ho.finite_difference_accel(state[i:i + 1].astype(np.float64), prev[i:i + 1].astype(np.float64), dt)
     comps, ratio = c_oracle.components(state[i:i + 1], acc, params[i:i + 1, :10], 1025.0, 9.81)
     c = comps[0]; p = state[i, :3].astype(np.float64)
@@ -59,7 +59,7 @@ if __name__ == "__main__":
     print("worst body: q", state[i, 3:7], "v", state[i, 7:10], "w", state[i, 10:13], "ratio", ratio[0])
     cmp("dragF", out[2:5], c[1]); cmp("liftF", out[5:8], c[2]); cmp("dragT", out[8:11], c[3]); cmp("amT", out[14:17], c[5])
     cmp("armb", out[17:20], c[6] - p); cmp("armp", out[20:23], c[7] - p)
-    cmp("armb x B", np.cross(out[17:20].astype(np.float64), [0, 0, out[1]]), np.cross(c[6] - p, c[0]))
+    cmp("armb x B", [out[27], out[28], 0.0], np.cross(c[6] - p, c[0]))
     cmp("dragarmT", out[23:26], np.cross(c[7] - p, c[1]))
     cmp("liftarmT", np.cross(out[20:23].astype(np.float64), out[5:8].astype(np.float64)), np.cross(c[7] - p, c[2]))
     print("  netT ref", rt[i] , "dT", t[i] - rt[i])
