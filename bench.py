@@ -18,6 +18,12 @@ per GPU, 7 coefficients stored fp16, fp32 arithmetic, 130 algorithmic bytes per
 body-step.  `--scenes` (default 4) independent scene replicas are stepped
 round-robin so that the bytes touched between two uses of any line exceed the
 256 MiB Infinity Cache (cache caveat): the rate is an HBM rate.
+The same line carries `roofline_4m` - the same kernel on 4 194 304 bodies
+(two rotating replicas, 1.1 GB), a size no cache can assist - and, for N > 1,
+`c4_strong`: BASELINE.json configs[3] as stated (262 144 bodies block-partitioned
+over the N GPUs) with the global kinetic energy sampled every 256 steps through
+`simulate.KineticEnergyMonitor` (device reduction + asynchronous all-reduce on a
+side stream).
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,7 +47,13 @@ from silver2_isaacsim_amd.engine import HydroEngine         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_CEILING_GBS = 6290.0    # measured float4-copy ceiling, same guide
-BYTES_PER_BODY = {"f32": 144, "f16": 130}    # SURVEY.md 8d / BASELINE.md 3
+BYTES_PER_BODY = {"f32": 144, "f16": 130}    # SURVEY.md 8d / BASELINE.md 3 (the algorithmic figure `frac` uses)
+# what the kernel really moves (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json): p_x, p_y are provably
+# unused by the wrench and never loaded, 8 B under the algorithmic figure
+TRAFFIC_BYTES_PER_BODY = {"f32": 136, "f16": 122}
+INFINITY_CACHE_BYTES = 256 << 20
+# resident bytes of one scene replica per body: state 52 + previous velocity 24 + parameters + wrench 24
+REPLICA_BYTES_PER_BODY = {"f32": 52 + 24 + 44 + 24, "f16": 52 + 24 + 30 + 24}
 
 WORKLOADS = {
     # name: (scene builder kwargs, coefficient dtype, description)
@@ -59,23 +71,33 @@ WORKLOADS = {
 BASELINE_CONFIG = {"c2": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}
 
 
+_SCENES: dict = {}
+DISTINCT_MAX = 1048576
+
+
 def build_scene(kind: str, n: int, seed: int):
+    """Scene of n bodies drawn from the law of SURVEY.md 8d.  Up to 1 048 576 bodies every body is DISTINCT (the
+    margin-gated generator takes ~2 s per million); larger scenes are permuted copies of the 1 048 576-body one."""
+    key = (kind, n, seed)
+    if key in _SCENES:
+        return _SCENES[key]
     if kind == "c2":
-        return scenes.scene_c2(n=n, seed=seed)
-    if kind == "c3":
-        return scenes.scene_c3(envs=n // len(scenes.C3_LINKS), seed=seed)
-    # the margin-gated generator costs ~15 s per million bodies: draw 256k and tile
-    base_n = min(n, 262144)
-    sc = scenes.scene_c5(n=base_n, seed=seed) if kind == "c5" else scenes.scene_c4(n=base_n, seed=seed)
-    if base_n < n:
-        reps = (n + base_n - 1) // base_n
-        rng = np.random.default_rng(seed + 1000)
-        parts_s, parts_p, parts_q = [], [], []
-        for _ in range(reps):
-            perm = rng.permutation(base_n)
-            parts_s.append(sc.state[perm]); parts_p.append(sc.prev[perm]); parts_q.append(sc.params[perm])
-        sc = scenes.Scene(sc.name, np.concatenate(parts_s)[:n], np.concatenate(parts_p)[:n],
-                          np.concatenate(parts_q)[:n], sc.rho, sc.g, sc.dt, sc.coeff_dtype, dict(sc.info, tiled=reps))
+        sc = scenes.scene_c2(n=n, seed=seed)
+    elif kind == "c3":
+        sc = scenes.scene_c3(envs=n // len(scenes.C3_LINKS), seed=seed)
+    else:
+        base_n = min(n, DISTINCT_MAX)
+        sc = scenes.scene_c5(n=base_n, seed=seed) if kind == "c5" else scenes.scene_c4(n=base_n, seed=seed)
+        if base_n < n:
+            reps = (n + base_n - 1) // base_n
+            rng = np.random.default_rng(seed + 1000)
+            perms = [rng.permutation(base_n) for _ in range(reps)]
+            sc = scenes.Scene(sc.name, np.concatenate([sc.state[p] for p in perms])[:n], np.concatenate([sc.prev[p] for p in perms])[:n],
+                              np.concatenate([sc.params[p] for p in perms])[:n], sc.rho, sc.g, sc.dt, sc.coeff_dtype,
+                              dict(sc.info, copies_of_distinct_population=reps))
+    if len(_SCENES) > 6:
+        _SCENES.clear()
+    _SCENES[key] = sc
     return sc
 
 
@@ -137,9 +159,10 @@ def spin_up(replicas, stream, seconds: float):
     torch.cuda.synchronize(dev)
 
 
-def timed_steps(replicas, steps: int, warmup: int, stream, world: int):
+def timed_steps(replicas, steps: int, warmup: int, stream, world: int, after_step=None):
     """W warm-up steps, then exactly K steps between barrier+synchronize pairs.  Returns
-    (wall seconds max over ranks, HIP-event milliseconds on the launch stream)."""
+    (wall seconds max over ranks, HIP-event milliseconds on the launch stream).
+    after_step(k, replica): called inside the timed region after step k (1-based)."""
     dev = replicas[0].state.device
     with torch.cuda.stream(stream):
         for k in range(warmup):
@@ -153,6 +176,8 @@ def timed_steps(replicas, steps: int, warmup: int, stream, world: int):
         ev0.record(stream)
         for k in range(steps):
             replicas[k % len(replicas)].step()
+            if after_step is not None:
+                after_step(k + 1, replicas[k % len(replicas)])
         ev1.record(stream)
     torch.cuda.synchronize(dev)
     hd.barrier()
@@ -225,6 +250,13 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
     }
 
 
+def residency(n: int, coeff: str, sets: int, bytes_per_body: int | None = None) -> dict:
+    """Where the rotating working set of a measurement lives.  Below 256 MiB it stays in the Infinity Cache between
+    two uses: the GB/s of such an entry is a CACHE rate, never an HBM fraction (SURVEY.md 8d cache caveat)."""
+    ws = sets * n * (bytes_per_body or REPLICA_BYTES_PER_BODY[coeff])
+    return {"working_set_bytes": ws, "resident": "infinity-cache" if ws < INFINITY_CACHE_BYTES else "hbm"}
+
+
 def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets: int = 4, seed: int = 11,
                layout: str = "tiled"):
     """Small untimed-contract measurement for the 'extras' block (not the headline)."""
@@ -236,7 +268,7 @@ def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets
         r.engine.close()
     us = ms * 1e3 / steps
     return {"n": sc.n, "coeff": coeff, "layout": layout, "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
-            "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
+            "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9, **residency(sc.n, coeff, sets)}
 
 
 def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int = 64, replays: int = 40, seed: int = 11):
@@ -269,7 +301,7 @@ def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int 
         r.engine.close()
     return {"n": sc.n, "coeff": coeff, "layout": "tiled", "mode": f"hipGraph x{steps_per_graph} steps",
             "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
-            "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9}
+            "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9, **residency(sc.n, coeff, 4)}
 
 
 def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 13):
@@ -306,7 +338,8 @@ def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 1
     for r in reps:
         r[0].close()
     return {"n": sc.n, "entry_point": "hydro_step_wrench_aos", "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
-            "algorithmic_gbs": sc.n * 168 / (us * 1e-6) / 1e9, "bytes_per_body_step": 168}
+            "algorithmic_gbs": sc.n * 168 / (us * 1e-6) / 1e9, "bytes_per_body_step": 168,
+            **residency(sc.n, "f32", sets, 12 + 16 + 24 + 24 + 24 + 44)}
 
 
 def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, implicit_drag: bool = False):
@@ -320,7 +353,77 @@ def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, i
     mode = "hipGraph x64 (hydro_step_fused_tiled)" if fused else "hipGraph x64 (wrench_tiled + integrate_tiled)"
     if implicit_drag:
         mode += ", implicit drag"
-    return {"n": n, "mode": mode, **r}
+    # ONE scene stepping on itself: state ping-pong (2 x 52 B) + parameters
+    return {"n": n, "mode": mode, **r, **residency(n, "f32", 1, 2 * 52 + 44)}
+
+
+def roofline_4m(dev, stream, coeff: str = "f16", n: int = 4194304, sets: int = 2, steps: int = 200):
+    """Second roofline object: the headline kernel on 4 194 304 bodies, two rotating replicas (1.1 GB): nothing of it
+    survives in the 256 MiB Infinity Cache between two uses, and ramp and drain of a launch weigh a quarter of what
+    they do at 1 048 576.  Same timing rule as the headline (HIP events on the launch stream over the timed steps)."""
+    r = quick_rate("c5" if coeff == "f16" else "c4", n, coeff, dev, stream, steps=steps, sets=sets, seed=5)
+    ach = r["algorithmic_gbs"]
+    tr = load_traffic(f"{coeff}_4m:tiled")
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": tr["hbm_bytes_per_launch"] if tr else None, "kernel": "wrench_tiled_kernel", "kernel_us": r["us_per_step"],
+           "bodies": r["n"], "coefficients": coeff, "algorithmic_bytes_per_launch": r["n"] * BYTES_PER_BODY[coeff],
+           "traffic_bytes_per_body": TRAFFIC_BYTES_PER_BODY[coeff],
+           "frac_traffic": r["n"] * TRAFFIC_BYTES_PER_BODY[coeff] / (r["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "working_set_bytes": r["working_set_bytes"], "resident": r["resident"], "steps": steps,
+           "scene": "4 permuted copies of the 1 048 576 distinct seed-5 bodies"}
+    if tr:
+        out["traffic_source"] = tr.get("source")
+    return out
+
+
+def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, ke_every: int = 256):
+    """BASELINE.json configs[3] as it is stated: 262 144 bodies (seed 4) block-partitioned over the GPUs, every rank
+    steps its contiguous shard (no data-path collective); the global kinetic energy is sampled every `ke_every`
+    steps by simulate.KineticEnergyMonitor: device reduction, asynchronous all-reduce (RCCL under backend nccl) on
+    a side stream, results picked up later by the host.  Same barrier / max-over-ranks timing as the headline."""
+    from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
+    full = build_scene("c4", 262144, 4)                      # the same scene on every rank ...
+    sc = full.shard(rank, world)                             # ... each keeps its contiguous block
+    reps = [Replica(sc, "f32", dev, roll=0) for _ in range(2)]      # two buffer sets of the SAME shard (cache-resident sizes)
+    mon = KineticEnergyMonitor(reps[0].engine, every=ke_every)
+    spin_up(reps, stream, 0.3)
+    wall, ev_ms = timed_steps(reps, steps, warmup, stream, world, after_step=lambda k, r: mon.observe(k, r.state, stream))
+    mon.collect(block=True)
+    for r in reps:
+        r.engine.close()
+    last = mon.last()
+    return {"value": full.n * steps / wall, "unit": "body-steps/s", "scaling": "strong", "baseline_config": "configs[3]",
+            "bodies_total": full.n, "bodies_this_rank": sc.n, "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": wall * 1e3 / steps, "kernel_us_rank0": ev_ms * 1e3 / steps,
+            "kinetic_energy": {"every_steps": ke_every, "samples": len(mon.samples), "host_waits": mon.waited_on_host,
+                               "last_step": last[0] if last else None, "global_J": last[1] if last else None,
+                               "how": "hydro_kinetic_energy_tiled on the step stream, all_reduce(async_op=True) + pinned copy on a side stream"},
+            **residency(sc.n, "f32", 2)}
+
+
+def plugin_rate(batched: bool = True, steps: int = 2000):
+    """Host cost of the plugin surface: the 20 prims of the main scene, each with its own HydrodynamicsBehavior on the
+    in-memory host of silver2_isaacsim_amd/testing.py; one physics step = 20 callbacks -> (batched) ONE
+    hydro_step_wrench_aos launch + one apply.  Wall time per physics step, GPU drained at the end."""
+    from silver2_isaacsim_amd import behavior as hb
+    from silver2_isaacsim_amd.testing import build_main_scene
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors = build_main_scene(batched)
+    for b in behaviors:
+        b.on_play()
+    for _ in range(100):
+        host.step(1.0 / 60.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        host.step(1.0 / 60.0)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / steps * 1e6
+    for b in behaviors:
+        b.on_stop()
+    hb.REGISTRY.clear()
+    return {"prims": len(prims), "batched": batched, "us_per_physics_step": us, "rtf_at_60hz": 1e6 / us / 60.0,
+            "apply_calls": world.apply_calls, "host": "silver2_isaacsim_amd.testing.FakeHost (in-memory; Isaac Sim cannot run on this box)"}
 
 
 def load_traffic(workload: str):
@@ -345,6 +448,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=4, help="scene replicas stepped round-robin per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-roofline-4m", action="store_true", help="skip the 4 194 304-body second roofline object (N=1 default run)")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N>1: skip the configs[3] strong-scaling leg")
     ap.add_argument("--extras-budget-seconds", type=float, default=150.0,
                     help="secondary measurements are skipped once this much time has gone into them")
     ap.add_argument("--bodies-per-lane", type=int, default=0)
@@ -416,6 +521,11 @@ def main():
     torch.cuda.synchronize(dev)
     ke_us = (time.perf_counter() - t0) * 1e6
 
+    # N > 1: BASELINE configs[3] as stated (262 144 bodies over the N GPUs, strong scaling) on every rank
+    strong = None
+    if world > 1 and not args.no_strong_leg:
+        strong = c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup)
+
     if rank == 0:
         traffic = load_traffic(f"{args.workload}:{args.layout}") if world == 1 and not args.bodies else None
         out = {
@@ -435,7 +545,13 @@ def main():
                          "kernel": "wrench_tiled_kernel" if args.layout == "tiled" else "wrench_soa_kernel",
                          "kernel_us": kernel_us,
                          "algorithmic_bytes_per_launch": sc.n * bpb,
-                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS},
+                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+                         # what the counters say: the kernel moves 122 B per body (fp16 coefficients), not the 130
+                         # algorithmic ones - frac_traffic is the honest bandwidth fraction
+                         "traffic_bytes_per_body": TRAFFIC_BYTES_PER_BODY[coeff],
+                         "frac_traffic": sc.n * TRAFFIC_BYTES_PER_BODY[coeff] / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_measured": "rocprofv3 --pmc passes committed under profiles/ (not re-measured in this run)",
+                         **residency(sc.n, coeff, args.scenes)},
             "spinup_seconds": args.spinup_seconds,
             "global_kinetic_energy_J": [float(x) for x in ke.cpu().tolist()],
             "ke_allreduce_us": ke_us,
@@ -450,6 +566,13 @@ def main():
                                        "sample": "failed", "error": repr(e)}
         else:
             out["cpu_baseline"] = None
+        if strong is not None:
+            out["c4_strong"] = strong
+        if world == 1 and args.workload == "c5" and not args.bodies and not args.no_roofline_4m:
+            try:
+                out["roofline_4m"] = roofline_4m(dev, stream)
+            except Exception as e:                          # noqa: BLE001 - report, never lose the line
+                out["roofline_4m"] = {"error": repr(e)}
         if world == 1 and not args.no_extras:
             # median of 5 runs (each 200 steps after 20 warm-up steps), same replicas
             try:
@@ -492,6 +615,8 @@ def main():
             guarded("plain_soa_c5_1048576", quick_rate, "c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
             guarded("plain_soa_f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
             guarded("aos_entry_1048576", aos_rate, 1048576, dev, stream)
+            guarded("plugin_20prims_us_per_step", plugin_rate, True)
+            guarded("plugin_20prims_per_prim_mode", plugin_rate, False, steps=500)
             guarded("closed_loop_c2_4096", closed_loop_rate, "c2", 4096)
             guarded("closed_loop_c2_4096_unfused", closed_loop_rate, "c2", 4096, fused=False)
             guarded("closed_loop_c3_1024envs_implicit", closed_loop_rate, "c3", 19456, implicit_drag=True)

@@ -83,7 +83,10 @@ int hydro_set_scene(hydro_t *h, double water_density, double gravity);
  *     any), not zeros (warp_hydrodynamics.py:59-61,290 vs numba_hydrodynamics.py:277-279).
  * Everything else is common (same matrix from the quaternion - Warp's quat_rotate differs from it by
  * 2(|q|^2-1), 2.4e-7 for an fp32-rounded unit quaternion; lift with a degenerate axis and the pressure
- * centre at rest, which the Warp source leaves unassigned, follow Numba / the N1 completion). */
+ * centre at rest, which the Warp source leaves unassigned, follow Numba / the N1 completion).
+ * PARITY UNPINNED for HYDRO_SEM_WARP: the mode restates warp_hydrodynamics.py from its source text - the reference
+ * holds no outputs of its Warp calculator and `warp` cannot be imported where this library is built.  The first call
+ * that selects it says so once on stderr (HYDRO_QUIET=1 in the environment silences it). */
 #define HYDRO_SEM_NUMBA 0
 #define HYDRO_SEM_WARP  1
 int hydro_set_semantics(hydro_t *h, int semantics);

@@ -69,18 +69,47 @@ class SimHost(Protocol):
 # --------------------------------------------------------------------------
 # batching registry
 # --------------------------------------------------------------------------
+class _AosStepper:
+    """`hydro_step_wrench_aos` on what a body view hands out, prepared once per set of device buffers.
+
+    A simulator's tensor API returns views of the SAME device buffers every physics step, so the launch is prepared
+    once (engine.prepare_step_wrench_aos: arguments validated, ctypes values built) and re-issued while the three
+    pointers stay the same; another device, dtype or layout, or new buffers, go through the conversions and a fresh
+    preparation.  Returns the positions tensor the kernel read (for apply_forces_and_torques_at_pos)."""
+
+    def __init__(self, engine: HydroEngine, force: torch.Tensor, torque: torch.Tensor):
+        self.engine, self.force, self.torque = engine, force, torque
+        self._key = None
+        self._step = None
+
+    def __call__(self, positions, orientations, velocities, dt: float):
+        key = (positions.data_ptr(), orientations.data_ptr(), velocities.data_ptr(), velocities.shape[0])
+        if key != self._key:
+            dev = self.engine.device
+            positions = positions.to(dev, torch.float32).contiguous()
+            orientations = orientations.to(dev, torch.float32).contiguous()
+            velocities = velocities.to(dev, torch.float32).contiguous()
+            self._step = self.engine.prepare_step_wrench_aos(positions, orientations, velocities,
+                                                             forces=self.force, torques=self.torque)
+            same = key == (positions.data_ptr(), orientations.data_ptr(), velocities.data_ptr(), velocities.shape[0])
+            self._key = key if same else None               # converted copies are good for this step only
+        self._step(dt)
+        return positions
+
+
 class _Group:
     """All registered prims that share one host and one (water density, gravity) pair."""
 
     def __init__(self, host: SimHost, rho: float, g: float, semantics: str = "numba"):
         self.host, self.rho, self.g, self.semantics = host, rho, g, semantics
         self.members: list["HydrodynamicsBehavior"] = []
-        self.pending: set[int] = set()
         self.view: BodyView | None = None
         self.engine: HydroEngine | None = None
         self.dirty = True
         self.steps = 0
         self.force = self.torque = None
+        self._stepper: _AosStepper | None = None
+        self.batches = 0                    # physics steps for which the batch has run (see EngineRegistry.on_step)
 
     def rebuild(self) -> None:
         if self.engine is not None:
@@ -97,6 +126,7 @@ class _Group:
         n = len(paths)
         self.force = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
         self.torque = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
+        self._stepper = _AosStepper(self.engine, self.force, self.torque)
         self.dirty = False
 
     def step(self, dt: float) -> None:
@@ -109,13 +139,9 @@ class _Group:
             velocities = self.view.get_velocities(clone=False)
             if velocities is None or velocities.shape[0] == 0:
                 return
-            dev = self.engine.device
-            positions = positions.to(dev).contiguous()
-            orientations = orientations.to(dev).contiguous()
-            velocities = velocities.to(dev).contiguous()
+            positions = self._stepper(positions, orientations, velocities, dt)
         except _STATE_FETCH_ERRORS:
             return
-        self.engine.step_wrench_aos(positions, orientations, velocities, dt, forces=self.force, torques=self.torque)
         self.view.apply_forces_and_torques_at_pos(forces=self.force, torques=self.torque,
                                                   positions=positions, is_global=True)
         self.steps += 1
@@ -139,7 +165,8 @@ class EngineRegistry:
             grp = self._groups[key] = _Group(b._host, b._rho, b._g, b.SEMANTICS)
         grp.members.append(b)
         grp.dirty = True
-        grp.pending.clear()
+        for m in grp.members:               # membership changed: everybody starts level with the batches run so far
+            m._callbacks = grp.batches
         return grp
 
     def unregister(self, b: "HydrodynamicsBehavior") -> None:
@@ -147,20 +174,21 @@ class EngineRegistry:
             if b in grp.members:
                 grp.members.remove(b)
                 grp.dirty = True
-                grp.pending.clear()
+                for m in grp.members:
+                    m._callbacks = grp.batches
                 if not grp.members:
                     grp.close()
                     del self._groups[key]
 
     @staticmethod
     def on_step(grp: _Group, b: "HydrodynamicsBehavior", dt: float) -> None:
-        """Called once per member per physics step.  The first caller of a step runs the batch."""
-        key = id(b)
-        if key in grp.pending:
-            grp.pending.discard(key)
-            return
-        grp.step(dt)
-        grp.pending = {id(m) for m in grp.members if m is not b}
+        """Called once per member per physics step.  The first caller of a step runs the batch: every member counts
+        its own callbacks, and the batch runs when a member's count gets ahead of the number of batches run (O(1) per
+        callback; a member the simulator skips for a while simply lags and never triggers)."""
+        b._callbacks += 1
+        if b._callbacks > grp.batches:
+            grp.batches = b._callbacks
+            grp.step(dt)
 
     def clear(self) -> None:
         for grp in self._groups.values():
@@ -193,6 +221,7 @@ class HydrodynamicsBehavior:
         self._batched = batched
         self._group: _Group | None = None
         self._engine: HydroEngine | None = None
+        self._callbacks = 0                 # physics-step callbacks received since the group last changed
 
     # -- lifecycle -----------------------------------------------------------
     def on_init(self):
@@ -276,6 +305,7 @@ class HydrodynamicsBehavior:
         self._hydro_calculator = self._engine
         self._force = torch.empty((1, 3), dtype=torch.float32, device=self._engine.device)
         self._torque = torch.empty((1, 3), dtype=torch.float32, device=self._engine.device)
+        self._stepper = _AosStepper(self._engine, self._force, self._torque)
         log.info("HydrodynamicsBehavior (HIP) initialized for %s", self._prim_path)
 
     def _apply_behavior(self, delta_time):
@@ -284,16 +314,11 @@ class HydrodynamicsBehavior:
             full_velocities = self._rigid_prim_view.get_velocities(clone=False)
             if full_velocities is None or full_velocities.shape[0] == 0:
                 return
-            dev = self._engine.device
-            positions = positions.to(dev).contiguous()
-            orientations = orientations.to(dev).contiguous()
-            full_velocities = full_velocities.to(dev).contiguous()
+            # quaternion reorder, finite-difference acceleration, model, lever arms, sum and clamp
+            # (hydrodynamics_behavior.py:194-226) are one kernel; the previous velocity lives in the engine
+            positions = self._stepper(positions, orientations, full_velocities, delta_time)
         except _STATE_FETCH_ERRORS:
             return
-        # quaternion reorder, finite-difference acceleration, model, lever arms, sum and clamp
-        # (hydrodynamics_behavior.py:194-226) are one kernel; the previous velocity lives in the engine
-        self._engine.step_wrench_aos(positions, orientations, full_velocities, delta_time,
-                                     forces=self._force, torques=self._torque)
         self._rigid_prim_view.apply_forces_and_torques_at_pos(
             forces=self._force, torques=self._torque, positions=positions, is_global=True)
 

@@ -11,12 +11,16 @@ field f (orders in include/hydro.h).
 from __future__ import annotations
 
 import ctypes
+import logging
 
 import numpy as np
 import torch
 
 from . import _native as nat
 from ._native import HydroError
+
+log = logging.getLogger("silver2_isaacsim_amd")
+_warp_mode_announced = False
 
 
 def _as_soa_tensor(x, fields: int, device: torch.device) -> torch.Tensor:
@@ -87,10 +91,18 @@ class HydroEngine:
 
     def set_semantics(self, semantics: str = "numba") -> None:
         """'numba' (default, the parity target) or 'warp': follow the reference's Warp twin where the two
-        calculators differ (added-mass rotation, centres of a dry body; include/hydro.h)."""
+        calculators differ (added-mass rotation, centres of a dry body; include/hydro.h).
+        PARITY UNPINNED for 'warp': that mode restates warp_hydrodynamics.py from its source text; the reference holds
+        no outputs of its Warp calculator and `warp` is not importable where this package is built.  Said once per
+        process through the package logger."""
+        global _warp_mode_announced
         code = {"numba": nat.HYDRO_SEM_NUMBA, "warp": nat.HYDRO_SEM_WARP}.get(semantics)
         if code is None:
             raise ValueError("semantics must be 'numba' or 'warp'")
+        if semantics == "warp" and not _warp_mode_announced:
+            _warp_mode_announced = True
+            log.warning("semantics='warp': restated from the source text of the reference's warp_hydrodynamics.py, no "
+                        "reference outputs behind it (parity unpinned); 'numba' is the verified mode")
         self._check(self._lib.hydro_set_semantics(self._h, code))
         self.semantics = semantics
 
@@ -302,6 +314,42 @@ class HydroEngine:
             self._h, n, positions.data_ptr(), orientations.data_ptr(), int(bool(quat_xyzw)), velocities.data_ptr(), float(dt),
             forces.data_ptr(), torques.data_ptr(), self._stream(stream)))
         return forces, torques
+
+    def prepare_step_wrench_aos(self, positions: torch.Tensor, orientations: torch.Tensor, velocities: torch.Tensor,
+                                forces: torch.Tensor | None = None, torques: torch.Tensor | None = None,
+                                quat_xyzw: bool = False):
+        """Validate the arguments of `step_wrench_aos` ONCE and return `step(dt, stream=None) -> (forces, torques)`,
+        which re-issues that launch on the same buffers (a simulator's tensor API hands out views of the same
+        device buffers every physics step).  For the plugin path, where the per-call Python work of
+        `step_wrench_aos` (five tensor checks, pointer conversions) is several times the kernel at 20 bodies.
+        `stream`: a torch stream / raw handle; None = the stream current at the time of the call."""
+        n = positions.shape[0]
+        for t, w in ((positions, 3), (orientations, 4), (velocities, 6)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, w) or t.device != self.device:
+                raise ValueError(f"expected contiguous float32 ({n},{w}) tensor on {self.device}")
+        if forces is None:
+            forces = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        if torques is None:
+            torques = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        for t in (forces, torques):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, 3) or t.device != self.device:
+                raise ValueError(f"expected contiguous float32 ({n},3) output on {self.device}")
+        fn, check = self._lib.hydro_step_wrench_aos, self._check
+        head = (self._h, ctypes.c_int64(n), ctypes.c_void_p(positions.data_ptr()), ctypes.c_void_p(orientations.data_ptr()),
+                ctypes.c_int(int(bool(quat_xyzw))), ctypes.c_void_p(velocities.data_ptr()))
+        tail = (ctypes.c_void_p(forces.data_ptr()), ctypes.c_void_p(torques.data_ptr()))
+        keep = (positions, orientations, velocities, forces, torques)          # the buffers must outlive the callable
+        dev, cur = self.device, torch.cuda.current_stream
+
+        def step(dt: float, stream=None):
+            if self._h is None:
+                raise HydroError(-5, "engine is closed")
+            sp = cur(dev).cuda_stream if stream is None else (stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+            rc = fn(*head, ctypes.c_double(dt), *tail, ctypes.c_void_p(sp))
+            if rc:
+                check(rc)
+            return keep[3], keep[4]
+        return step
 
     def step_components(self, state: torch.Tensor, accel: torch.Tensor, out: torch.Tensor | None = None,
                         ratio: torch.Tensor | None = None, stream=None):

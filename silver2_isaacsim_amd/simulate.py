@@ -17,13 +17,116 @@ import time
 import numpy as np
 import torch
 
+from . import distributed as hd
 from . import scenes
 from .engine import HydroEngine
 
 
+class KineticEnergyMonitor:
+    """The one collective of the path: global kinetic energy, off the step path.
+
+    Every `every` steps the rank's shard is reduced ON DEVICE to one float64 pair [translational, rotational]
+    (`hydro_kinetic_energy*`: wave64 shuffles -> LDS -> one partial per block -> fixed-order second stage), on
+    the stream the steps run on.  The pair is then summed over the ranks on a SIDE stream -
+    `all_reduce(async_op=True)`, RCCL over xGMI under backend "nccl" (16 bytes: latency, not bandwidth), gloo on a
+    pinned host copy otherwise - and copied to pinned host memory.  The step stream never waits for any of it; the
+    host picks a sample up `every` steps later (`collect()`), when it has long arrived.  The reference has no
+    counterpart (single process, no reduction of any kind); its oracle is an fp64 NumPy sum.
+
+    `reduce_local(out)` writes the rank's float64 pair into `out` (a tensor on `device`) using the current stream;
+    the default is `engine.kinetic_energy(state, rotational, out=out)` on the state passed to `observe`."""
+
+    def __init__(self, engine: HydroEngine | None = None, every: int = 64, rotational: bool = True, slots: int = 4,
+                 device: torch.device | str | None = None, reduce_local=None):
+        if every <= 0 or slots < 2:
+            raise ValueError("every must be positive, slots at least 2")
+        self.engine, self.every, self.rotational = engine, int(every), bool(rotational)
+        self.device = torch.device(device) if device is not None else engine.device
+        self._reduce_local = reduce_local
+        self._gpu = self.device.type == "cuda"
+        self._nccl = self._gpu and hd.collective_device(self.device).type == "cuda"
+        self._dev = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(slots)]
+        self._host = [torch.zeros(2, dtype=torch.float64, pin_memory=self._gpu) for _ in range(slots)]
+        self._side = torch.cuda.Stream(self.device) if self._gpu else None
+        self._pending: list = []              # (step, slot, work handle or None, completion event or None)
+        self._next_slot = 0
+        self.samples: list = []               # (step, [translational, rotational]) in submission order
+        self.submitted = 0
+        self.waited_on_host = 0               # samples the host had to wait for (0 when `every` covers the latency)
+
+    def observe(self, step: int, state: torch.Tensor | None = None, stream=None) -> bool:
+        """Call after physics step `step` (1-based count of completed steps) with the state that step produced.
+        Submits a sample when `step` is a multiple of `every`; returns True if it did."""
+        if step % self.every:
+            return False
+        self.collect(block_oldest=len(self._pending) >= len(self._dev) - 1)      # free a slot if the ring is full
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % len(self._dev)
+        dev_buf, host_buf = self._dev[slot], self._host[slot]
+        if self._gpu:
+            stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(stream):
+                self._local(state, dev_buf)
+                ready = torch.cuda.Event()
+                ready.record(stream)
+            self._side.wait_event(ready)                    # the side stream, not the host, waits for the reduction
+            work = None
+            with torch.cuda.stream(self._side):
+                if self._nccl:
+                    work = hd.all_reduce_sum_(dev_buf, async_op=True)
+                    if work is not None:
+                        work.wait()                         # orders the SIDE stream after RCCL's; the host does not block
+                host_buf.copy_(dev_buf, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            self._pending.append((step, slot, None if self._nccl else "gloo", done))
+        else:
+            self._local(state, dev_buf)
+            host_buf.copy_(dev_buf)
+            self._pending.append((step, slot, hd.all_reduce_sum_(host_buf, async_op=True), None))
+        self.submitted += 1
+        return True
+
+    def _local(self, state, out) -> None:
+        if self._reduce_local is not None:
+            self._reduce_local(out)
+        else:
+            self.engine.kinetic_energy(state, self.rotational, out=out)
+
+    def collect(self, block: bool = False, block_oldest: bool = False) -> list:
+        """Move finished samples to `samples` (all of them, waiting if need be, with block=True)."""
+        out = []
+        while self._pending:
+            step, slot, work, done = self._pending[0]
+            must = block or block_oldest or work == "gloo"      # (gloo ranks must reach their all-reduce in step)
+            if done is not None:                            # GPU: the pinned copy is complete when `done` has fired
+                if not done.query():
+                    if not must:
+                        break
+                    self.waited_on_host += 1
+                    done.synchronize()
+                if work == "gloo":                          # ranks share nothing but the host here (tests, rehearsals)
+                    hd.all_reduce_sum_(self._host[slot])
+            elif work is not None:                          # CPU + gloo: asynchronous handle
+                if not work.is_completed():
+                    if not must:
+                        break
+                    self.waited_on_host += 1
+                work.wait()
+            self._pending.pop(0)
+            block_oldest = False
+            sample = (step, [float(x) for x in self._host[slot].tolist()])
+            self.samples.append(sample)
+            out.append(sample)
+        return out
+
+    def last(self):
+        return self.samples[-1] if self.samples else None
+
+
 class ClosedLoopSim:
     def __init__(self, scene: "scenes.Scene", device: int | str = 0, coeff_dtype: str | None = None,
-                 fused: bool = True, implicit_drag: bool = False):
+                 fused: bool = True, implicit_drag: bool = False, ke_every: int = 0):
         if implicit_drag and not fused:
             raise ValueError("implicit drag needs the fused step (the drag coefficients never leave the kernel)")
         self.implicit_drag = implicit_drag
@@ -43,6 +146,9 @@ class ClosedLoopSim:
         self.steps_done = 0
         self._graph = None
         self._graph_steps = 0
+        # optional global kinetic energy every `ke_every` steps (asynchronous, see KineticEnergyMonitor); with HIP-graph
+        # replays the sampling points are the replay boundaries, so `ke_every` should be a multiple of graph_steps
+        self.monitor = KineticEnergyMonitor(self.engine, every=ke_every) if ke_every else None
 
     # one physics step on the current stream context
     def _step_once(self) -> None:
@@ -58,7 +164,9 @@ class ClosedLoopSim:
         with torch.cuda.stream(self.stream):
             for _ in range(steps):
                 self._step_once()
-        self.steps_done += steps
+                self.steps_done += 1
+                if self.monitor:
+                    self.monitor.observe(self.steps_done, self.cur, self.stream)
 
     def _capture(self, graph_steps: int) -> None:
         if graph_steps % 2:
@@ -79,7 +187,9 @@ class ClosedLoopSim:
             with torch.cuda.stream(self.stream):
                 for _ in range(steps // graph_steps):
                     self._graph.replay()
-            self.steps_done += (steps // graph_steps) * graph_steps
+                    self.steps_done += graph_steps
+                    if self.monitor:
+                        self.monitor.observe(self.steps_done, self.cur, self.stream)
             steps %= graph_steps
         if steps:
             self.run_eager(steps)

@@ -25,7 +25,7 @@ class FakeWorld:
         self.orientations = torch.zeros((0, 4), device=self.device)     # wxyz
         self.velocities = torch.zeros((0, 6), device=self.device)
         self.masses = torch.zeros((0,), device=self.device)
-        self.applied: dict[str, tuple[torch.Tensor, torch.Tensor]] = {}
+        self.applied = _Applied()
         self.apply_calls = 0
 
     def add_body(self, path: str, position, orientation_wxyz, velocity6, mass: float) -> int:
@@ -41,8 +41,27 @@ class FakeWorld:
         return self.paths.index(path)
 
 
+class _Applied:
+    """`world.applied[path]` -> (force, torque) the simulator last received for that prim.  Views register which
+    row of which batch a prim is; rows are sliced out when somebody looks, not on every physics step."""
+
+    def __init__(self):
+        self._where: dict[str, tuple["FakeRigidView", int]] = {}
+
+    def __getitem__(self, path: str):
+        view, k = self._where[path]
+        if view._force is None:
+            raise KeyError(path)
+        return view._force[k].clone(), view._torque[k].clone()
+
+    def __contains__(self, path: str) -> bool:
+        return path in self._where and self._where[path][0]._force is not None
+
+
 class FakeRigidView:
-    """The six RigidPrimView methods the plugin uses, over a FakeWorld."""
+    """The six RigidPrimView methods the plugin uses, over a FakeWorld.  Like the simulator's tensor API it hands
+    out the SAME device buffers every physics step (refreshed in place from the world's state), and it consumes the
+    applied wrench with two device copies."""
 
     def __init__(self, world: FakeWorld, prim_paths: Sequence[str], name: str):
         self.world, self.name = world, name
@@ -50,6 +69,11 @@ class FakeRigidView:
         self.paths = list(prim_paths)
         self._ok = False
         self.fail_next_fetch = False
+        n = len(self.paths)
+        self._pos = torch.empty((n, 3), device=world.device)
+        self._quat = torch.empty((n, 4), device=world.device)
+        self._vel = torch.empty((n, 6), device=world.device)
+        self._force = self._torque = None
 
     def initialize(self):
         self._ok = True
@@ -61,18 +85,25 @@ class FakeRigidView:
         if self.fail_next_fetch:
             self.fail_next_fetch = False
             raise RuntimeError("simulated tensor API failure")
-        return self.world.positions[self.idx], self.world.orientations[self.idx]
+        torch.index_select(self.world.positions, 0, self.idx, out=self._pos)
+        torch.index_select(self.world.orientations, 0, self.idx, out=self._quat)
+        return (self._pos.clone(), self._quat.clone()) if clone else (self._pos, self._quat)
 
     def get_velocities(self, clone=False):
-        return self.world.velocities[self.idx]
+        torch.index_select(self.world.velocities, 0, self.idx, out=self._vel)
+        return self._vel.clone() if clone else self._vel
 
     def get_masses(self, clone=False):
         return self.world.masses[self.idx]
 
     def apply_forces_and_torques_at_pos(self, forces=None, torques=None, positions=None, is_global=True):
         self.world.apply_calls += 1
-        for k, p in enumerate(self.paths):
-            self.world.applied[p] = (forces[k].clone(), torques[k].clone())
+        if self._force is None:
+            self._force, self._torque = torch.empty_like(forces), torch.empty_like(torques)
+            for k, p in enumerate(self.paths):
+                self.world.applied._where[p] = (self, k)
+        self._force.copy_(forces)
+        self._torque.copy_(torques)
 
 
 class FakeHost:
@@ -122,3 +153,33 @@ class FakeHost:
     def step(self, dt: float):
         for cb in list(self._subs):
             cb(dt)
+
+
+MAIN_SCENE = ["Obsea_Buoy", "Body"] + [f"{p}_{i}" for p in ("Coxa", "Femur", "Tibia") for i in range(6)]
+
+
+def build_main_scene(batched: bool = True, config_path: str | None = None, seed: int = 0, device: str = "cuda:0"):
+    """The 20 prims of silver2_isaac_sim.usd that carry the behavior, each with its own
+    `HydrodynamicsBehavior` on an in-memory host: (world, host, prims, behaviors), `on_init` done."""
+    import numpy as np
+    from . import behavior as hb
+    rng = np.random.default_rng(seed)
+    world = FakeWorld(device)
+    host = FakeHost(world, config_path)
+    prims, behaviors = [], []
+    for name in MAIN_SCENE:
+        buoy = name == "Obsea_Buoy"
+        initial = {"xDimension": 1, "yDimension": 1, "zDimension": 3} if buoy else None
+        prim = AttributeStore(name, f"/World/{'Environment' if buoy else 'SILVER2'}/{name}")
+        pos = (-7, 40, 0.596) if buoy else tuple(np.array([2.0, 10.7, -18.44]) + rng.uniform(-0.3, 0.3, 3))
+        q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
+        vel = np.concatenate([rng.normal(0, 0.2, 3), rng.normal(0, 0.3, 3)])
+        part = cfg.match_part(name, cfg.PART_TABLE)
+        world.add_body(prim.path, pos, q, vel, cfg.PART_MASS.get(part, 700.0))
+        b = hb.HydrodynamicsBehavior(prim, host, batched=batched)
+        b.on_init()
+        if initial:                                   # authored USD values for the buoy (no JSON part matches it)
+            for k, v in initial.items():
+                host.set_exposed_variable(prim, cfg.full_attr_name(k), v)
+        prims.append(prim); behaviors.append(b)
+    return world, host, prims, behaviors

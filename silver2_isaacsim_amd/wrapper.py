@@ -15,7 +15,8 @@ shape (N,3) that are views of wrapper-owned buffers, valid until the next call
 (warp_hydrodynamics_wrapper.py:123-132).  Values follow the Numba path where the
 two references disagree (SURVEY.md notes N3, N4, N6) unless `semantics="warp"` is
 passed, which reproduces the Warp twin's added-mass rotation (N3) and dry-body
-centres (N6) instead.  The ninth value of the Numba tuple, the submersion ratio,
+centres (N6) instead - PARITY UNPINNED for that mode (restated from source text;
+the reference holds no outputs of its Warp calculator).  The ninth value of the Numba tuple, the submersion ratio,
 is kept in `self.sub_ratio`.
 """
 from __future__ import annotations

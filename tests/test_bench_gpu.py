@@ -28,6 +28,8 @@ def test_bench_json_contract(native_built):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert r["traffic_bytes_per_body"] == 122 and r["frac_traffic"] == pytest.approx(r["frac"] * 122 / 130)
+    assert r["resident"] in ("hbm", "infinity-cache") and "roofline_4m" not in d      # 65 536 bodies x 4: a cache-resident test size
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert c["gpu_vs_oracle_max_rel_err"] <= 1e-5 and c["gpu_vs_oracle_n_over_1e-5"] == 0     # the CPU leg is also the checker
@@ -54,3 +56,28 @@ def test_bench_two_ranks_share_the_gpu(native_built):
     assert d["config"]["bodies_per_gpu"] == 65536 and "x2" in d["config"]["sharding"]
     assert d["value"] == pytest.approx(2 * 65536 * 40 / (d["ms_per_step"] * 1e-3 * 40), rel=1e-6)
     assert len(d["global_kinetic_energy_J"]) == 2 and d["global_kinetic_energy_J"][0] > 0
+    # N > 1 also runs BASELINE configs[3] as stated: 262 144 bodies block-partitioned over the ranks (strong scaling),
+    # with the global kinetic energy sampled by the asynchronous monitor
+    cs = d["c4_strong"]
+    assert cs["scaling"] == "strong" and cs["baseline_config"] == "configs[3]" and cs["n_gpus"] == 2
+    assert cs["bodies_total"] == 262144 and cs["bodies_this_rank"] == 131072
+    assert cs["value"] == pytest.approx(262144 * 40 / (cs["ms_per_step"] * 1e-3 * 40), rel=1e-6)
+    ke = cs["kinetic_energy"]
+    assert ke["every_steps"] == 256 and ke["samples"] == 0        # 40 steps: no sampling point reached ...
+    # ... so check the monitor itself against the fp64 host sum over ALL 262 144 bodies in a second, longer run
+    with socket.socket() as s2:
+        s2.bind(("127.0.0.1", 0)); port2 = s2.getsockname()[1]
+    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port2), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "600", "--warmup", "8",
+            "--bodies", "65536", "--spinup-seconds", "0.1"]
+    res2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, env=env)
+    assert res2.returncode == 0, res2.stderr[-3000:]
+    ke2 = json.loads([l for l in res2.stdout.splitlines() if l.strip()][0])["c4_strong"]["kinetic_energy"]
+    assert ke2["samples"] == 2 and ke2["last_step"] == 512
+    import numpy as np
+    sys.path.insert(0, REPO)
+    from silver2_isaacsim_amd import scenes
+    sc = scenes.scene_c4(n=262144, seed=4)
+    m = sc.params[:, 10].astype(np.float64)
+    lin = float((0.5 * m * (sc.state[:, 7:10].astype(np.float64) ** 2).sum(1)).sum())
+    assert ke2["global_J"][0] == pytest.approx(lin, rel=1e-12)

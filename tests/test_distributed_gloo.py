@@ -73,3 +73,65 @@ def test_single_process_helpers_are_noops():
     hd.barrier()
     with pytest.raises(TypeError):
         hd.global_kinetic_energy(torch.tensor([1.0], dtype=torch.float32))
+
+
+def _monitor_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from silver2_isaacsim_amd import distributed as hd
+    from silver2_isaacsim_amd import scenes
+    from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
+    assert hd.init_process_group(backend="gloo")
+    sc = scenes.scene_c4(n=262144 // 64, seed=4)              # BASELINE configs[3] population, scaled down
+    mine = sc.shard(rank, world)
+    m = mine.params[:, 10].astype(np.float64)
+    vel = mine.state[:, 7:10].astype(np.float64)
+    step = {"k": 0}
+
+    def reduce_local(out):                                    # stands in for hydro_kinetic_energy on this CPU-only box
+        v = vel * (1.0 + 0.01 * step["k"])                    # the "state" changes from sample to sample
+        out[0] = float((0.5 * m * (v ** 2).sum(1)).sum()); out[1] = 0.0
+    mon = KineticEnergyMonitor(None, every=8, device="cpu", reduce_local=reduce_local)
+    for k in range(1, 41):                                    # 40 steps -> 5 samples, collected lazily
+        step["k"] = k
+        mon.observe(k)
+    mon.collect(block=True)
+    mt = sc.params[:, 10].astype(np.float64); vt = sc.state[:, 7:10].astype(np.float64)
+    want = [float((0.5 * mt * ((vt * (1.0 + 0.01 * k)) ** 2).sum(1)).sum()) for k in (8, 16, 24, 32, 40)]
+    q.put((rank, [s for s, _ in mon.samples], [v[0] for _, v in mon.samples], want, mon.submitted))
+    hd.barrier()
+    dist.destroy_process_group()
+
+
+def test_kinetic_energy_monitor_two_ranks():
+    """SURVEY 8e as designed: per-rank reduce every K steps, asynchronous all-reduce, results picked up later;
+    the global value equals the fp64 host sum over ALL bodies to 1e-12 on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_monitor_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, steps, got, want, submitted in res:
+        assert steps == [8, 16, 24, 32, 40] and submitted == 5
+        assert got == pytest.approx(want, rel=1e-12)
+
+
+def test_kinetic_energy_monitor_single_process_cadence():
+    from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
+    calls = []
+
+    def reduce_local(out):
+        calls.append(1); out[0] = float(len(calls)); out[1] = 0.5
+    mon = KineticEnergyMonitor(None, every=4, device="cpu", reduce_local=reduce_local, slots=2)
+    assert [mon.observe(k) for k in range(1, 13)] == [False, False, False, True] * 3
+    mon.collect(block=True)
+    assert mon.samples == [(4, [1.0, 0.5]), (8, [2.0, 0.5]), (12, [3.0, 0.5])] and mon.last()[0] == 12
+    with pytest.raises(ValueError):
+        KineticEnergyMonitor(None, every=0, device="cpu", reduce_local=reduce_local)

@@ -1,0 +1,140 @@
+"""Argument errors of the tiled / fused / array-of-structs / layout entry points (SURVEY.md 8b "Errors" row): each
+must come back as HYDRO_E_ARG with a message in hydro_last_error, launch nothing, and leave the engine usable.
+Called through the raw C ABI (ctypes), the way a foreign host would."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from silver2_isaacsim_amd import _native as nat
+from silver2_isaacsim_amd import scenes
+from silver2_isaacsim_amd.engine import HydroEngine
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+E_ARG = -1
+N = 1000                      # 16 tiles
+ST, PV, WR = 13 * 64, 6 * 64, 6 * 64
+
+
+@pytest.fixture()
+def rig(native_built):
+    fx = load_golden("c4")
+    eng = HydroEngine(8192, DEV, float(fx["rho"]), float(fx["g"]))
+    eng.set_params(fx["params"][:N])
+    state = torch.from_numpy(scenes.to_tiled(fx["state"][:N])).to(DEV)
+    prev = torch.from_numpy(scenes.to_tiled(fx["prev"][:N])).to(DEV)
+    out = eng.alloc_tiled(6, N)
+    sentinel = torch.full_like(out, 7.0)
+    out.copy_(sentinel)
+    yield eng, state, prev, out, float(fx["dt"])
+    # nothing was launched by any failing call: the output buffer still holds the sentinel ...
+    torch.cuda.synchronize()
+    assert torch.equal(out, sentinel)
+    # ... and the engine still works
+    good = eng.step_wrench_tiled(state, N, float(fx["dt"]), prev=prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(good).all()
+    eng.close()
+
+
+def _expect_arg(eng, rc, needle):
+    assert rc == E_ARG, nat.STATUS_NAMES.get(rc, rc)
+    msg = eng._lib.hydro_last_error(eng._h).decode()
+    assert needle in msg, msg
+
+
+def p(t, byte_offset=0):
+    return ctypes.c_void_p(t.data_ptr() + byte_offset)
+
+
+def test_tiled_stride_and_alignment_errors(rig):
+    eng, state, prev, out, dt = rig
+    L, h = eng._lib, eng._h
+    step = lambda st=p(state), ss=ST, pv=p(prev), ps=PV, o=p(out), os_=WR: L.hydro_step_wrench_tiled(h, N, st, ss, pv, ps, dt, o, os_, None)   # noqa: E731
+    _expect_arg(eng, step(ss=ST - 64), "tile stride")                 # stride < fields * 64
+    _expect_arg(eng, step(ps=PV - 4), "tile stride")
+    _expect_arg(eng, step(os_=WR - 64), "tile stride")
+    _expect_arg(eng, step(ss=1 << 24), "tile stride")                 # stride >= 2^24 (24-bit multiplies in the kernel)
+    _expect_arg(eng, step(ss=ST + 2), "tile stride")                  # not a multiple of 4 floats
+    _expect_arg(eng, step(st=p(state, 4)), "16-byte aligned")         # misaligned base pointers
+    _expect_arg(eng, step(pv=p(prev, 8)), "16-byte aligned")
+    _expect_arg(eng, step(o=p(out, 4)), "16-byte aligned")
+    _expect_arg(eng, step(st=None), "null state")
+    _expect_arg(eng, step(o=None), "null wrench")
+    # tiled buffer of 4 GiB or more: 32-bit byte offsets in the kernels.  Argument check only - the pointer is never
+    # dereferenced: 4 160 bodies = 65 tiles x (2^24 - 4) floats x 4 B >= 2^32
+    eng.set_params(np.tile(load_golden("c4")["params"], (2, 1))[:4160])
+    rc = L.hydro_step_wrench_tiled(h, 4160, p(state), (1 << 24) - 4, p(prev), PV, dt, p(out), WR, None)
+    _expect_arg(eng, rc, "4 GiB")
+    rc = L.hydro_step_wrench_tiled(h, N, p(state), ST, p(prev), PV, 0.0, p(out), WR, None)
+    _expect_arg(eng, rc, "dt must be > 0")
+
+
+def test_fused_step_errors(rig):
+    eng, state, prev, out, dt = rig
+    L, h = eng._lib, eng._h
+    old = torch.zeros_like(state)
+    pv = p(old, 7 * 64 * 4)
+
+    def fused(st=p(state), ss=ST, pvp=pv, ps=ST, so=p(old), sos=ST, w=p(out), ws=WR):
+        return L.hydro_step_fused_tiled(h, N, st, ss, pvp, ps, dt, so, sos, w, ws, 0, None)
+    _expect_arg(eng, fused(so=p(state)), "must not alias state")      # state_out == state
+    _expect_arg(eng, fused(ss=ST - 4), "tile stride")
+    _expect_arg(eng, fused(ps=PV - 4), "tile stride")
+    _expect_arg(eng, fused(sos=ST - 64), "tile stride")
+    _expect_arg(eng, fused(ws=WR + 1), "tile stride")
+    _expect_arg(eng, fused(sos=1 << 24), "tile stride")
+    _expect_arg(eng, fused(pvp=None), "null prev")
+    _expect_arg(eng, fused(so=None), "null state_out")
+    _expect_arg(eng, fused(st=p(state, 4)), "16-byte aligned")
+    _expect_arg(eng, fused(so=p(old, 8)), "16-byte aligned")
+    rc = L.hydro_integrate_tiled(h, N, p(state), ST - 64, p(out), WR, dt, p(old), ST, None)
+    _expect_arg(eng, rc, "tile stride")
+    rc = L.hydro_integrate_tiled(h, N, p(state), ST, p(out), WR, dt, p(old, 4), ST, None)
+    _expect_arg(eng, rc, "16-byte aligned")
+    torch.cuda.synchronize()
+    assert not old.any()                                              # nothing was written
+
+
+def test_array_of_structs_and_layout_errors(rig):
+    eng, state, prev, out, dt = rig
+    L, h = eng._lib, eng._h
+    pos = torch.zeros((N + 4, 3), device=DEV); quat = torch.zeros((N + 4, 4), device=DEV); quat[:, 0] = 1
+    vel = torch.zeros((N + 4, 6), device=DEV)
+    f = torch.full((N + 4, 3), 7.0, device=DEV); t = torch.full((N + 4, 3), 7.0, device=DEV)
+
+    def aos(n=N, a=p(pos), b=p(quat), c=p(vel), d=p(f), e=p(t), dt_=dt):
+        return L.hydro_step_wrench_aos(h, n, a, b, 0, c, dt_, d, e, None)
+    _expect_arg(eng, aos(a=p(pos, 4)), "16-byte aligned")             # every tensor is read / written in 16-byte chunks
+    _expect_arg(eng, aos(b=p(quat, 8)), "16-byte aligned")
+    _expect_arg(eng, aos(c=p(vel, 4)), "16-byte aligned")
+    _expect_arg(eng, aos(d=p(f, 12)), "16-byte aligned")
+    _expect_arg(eng, aos(e=p(t, 4)), "16-byte aligned")
+    _expect_arg(eng, aos(a=None), "null tensor")
+    _expect_arg(eng, aos(dt_=-1.0), "dt must be > 0")
+    _expect_arg(eng, aos(n=(1 << 26) + 1), "2^26")                    # checked before anything else about n
+    _expect_arg(eng, aos(n=-1), "n out of range")
+    torch.cuda.synchronize()
+    assert (f == 7.0).all() and (t == 7.0).all()
+    # layout edges
+    tiled_state = eng.alloc_tiled(13, N)
+    _expect_arg(eng, L.hydro_pack_state_aos(h, N, p(pos, 4), p(quat), 0, p(vel), p(tiled_state), ST, None), "16-byte aligned")
+    _expect_arg(eng, L.hydro_pack_state_aos(h, N, p(pos), p(quat), 0, p(vel), p(tiled_state), ST - 64, None), "tile stride")
+    _expect_arg(eng, L.hydro_pack_state_aos(h, N, p(pos), None, 0, p(vel), p(tiled_state), ST, None), "null tensor")
+    _expect_arg(eng, L.hydro_pack_state_aos(h, 8193, p(pos), p(quat), 0, p(vel), p(tiled_state), ST, None), "n out of range")
+    _expect_arg(eng, L.hydro_unpack_wrench_aos(h, N, p(out), WR, p(f, 4), p(t), None), "16-byte aligned")
+    _expect_arg(eng, L.hydro_unpack_wrench_aos(h, N, p(out), WR - 4, p(f), p(t), None), "tile stride")
+    _expect_arg(eng, L.hydro_unpack_wrench_aos(h, N, p(out), WR, None, p(t), None), "null tensor")
+    soa = torch.zeros((13, N), device=DEV)
+    tab = nat.pointer_table([soa.data_ptr() + k * N * 4 for k in range(13)])
+    _expect_arg(eng, L.hydro_repack(h, N, 13, tab, p(tiled_state), ST - 64, 1, None), "tile stride")
+    _expect_arg(eng, L.hydro_repack(h, N, 25, tab, p(tiled_state), 25 * 64, 1, None), "bad arguments")      # > 24 fields
+    _expect_arg(eng, L.hydro_repack(h, N, 13, tab, p(tiled_state, 4), ST, 1, None), "16-byte aligned")
+    bad = nat.pointer_table([soa.data_ptr() + k * N * 4 if k != 5 else 0 for k in range(13)])
+    _expect_arg(eng, L.hydro_repack(h, N, 13, bad, p(tiled_state), ST, 1, None), "null field pointer")
+    _expect_arg(eng, L.hydro_kinetic_energy_tiled(h, N, p(state), ST - 64, 0, p(torch.zeros(2, dtype=torch.float64, device=DEV)), None), "tile stride")
+    torch.cuda.synchronize()
+    assert not tiled_state.any() and (f == 7.0).all()

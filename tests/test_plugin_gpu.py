@@ -13,31 +13,12 @@ from silver2_isaacsim_amd.testing import FakeHost, FakeWorld
 from silver2_isaacsim_amd.wrapper import HipHydrodynamicsWrapper
 
 pytestmark = pytest.mark.gpu
-MAIN_SCENE = ["Obsea_Buoy", "Body"] + [f"{p}_{i}" for p in ("Coxa", "Femur", "Tibia") for i in range(6)]
+from silver2_isaacsim_amd.testing import MAIN_SCENE, build_main_scene      # noqa: E402
 
 
 def build_scene(batched, config_path=None, seed=0):
     """The 20 prims of silver2_isaac_sim.usd that carry the behavior."""
-    rng = np.random.default_rng(seed)
-    world = FakeWorld("cuda:0")
-    host = FakeHost(world, config_path)
-    prims, behaviors = [], []
-    for name in MAIN_SCENE:
-        buoy = name == "Obsea_Buoy"
-        initial = {"xDimension": 1, "yDimension": 1, "zDimension": 3} if buoy else None
-        prim = cfg.AttributeStore(name, f"/World/{'Environment' if buoy else 'SILVER2'}/{name}")
-        pos = (-7, 40, 0.596) if buoy else tuple(np.array([2.0, 10.7, -18.44]) + rng.uniform(-0.3, 0.3, 3))
-        q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
-        vel = np.concatenate([rng.normal(0, 0.2, 3), rng.normal(0, 0.3, 3)])
-        part = cfg.match_part(name, cfg.PART_TABLE)
-        world.add_body(prim.path, pos, q, vel, cfg.PART_MASS.get(part, 700.0))
-        b = hb.HydrodynamicsBehavior(prim, host, batched=batched)
-        b.on_init()
-        if initial:                                   # authored USD values for the buoy (no JSON part matches it)
-            for k, v in initial.items():
-                host.set_exposed_variable(prim, cfg.full_attr_name(k), v)
-        prims.append(prim); behaviors.append(b)
-    return world, host, prims, behaviors
+    return build_main_scene(batched, config_path, seed)
 
 
 def oracle_wrench(world, prims, host, prev6, dt, semantics="numba"):
