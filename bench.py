@@ -14,7 +14,8 @@ the one RCCL call is the global kinetic-energy all-reduce after the timed loop.
 
 Workload (default `c5` = BASELINE.json configs[4], the configuration the
 "% of HBM roofline" part of the metric is quoted on): 1 048 576 synthetic bodies
-per GPU, 7 coefficients stored fp16, fp32 arithmetic, 130 algorithmic bytes per
+per GPU, fp32 state, 7 coefficients stored fp16, fp64 arithmetic (the reference's
+Numba path is float64; results are rounded to fp32 once), 130 algorithmic bytes per
 body-step.  `--scenes` (default 4) independent scene replicas are stepped
 round-robin so that the bytes touched between two uses of any line exceed the
 256 MiB Infinity Cache (cache caveat): the rate is an HBM rate.
@@ -57,7 +58,7 @@ REPLICA_BYTES_PER_BODY = {"f32": 52 + 24 + 44 + 24, "f16": 52 + 24 + 30 + 24}
 
 WORKLOADS = {
     # name: (scene builder kwargs, coefficient dtype, description)
-    "c5": ("c5", 1048576, "f16", "C5: 1 048 576 bodies/GPU, fp16 coefficients, fp32 arithmetic"),
+    "c5": ("c5", 1048576, "f16", "C5: 1 048 576 bodies/GPU, fp32 state, fp16-stored coefficients, fp64 arithmetic rounded to fp32 once"),
     "c5-f32": ("c4", 1048576, "f32", "C5 population with fp32 coefficients (144 B/body-step)"),
     "c4": ("c4", 262144, "f32", "C4: 262 144 bodies (per GPU under weak scaling)"),
     "c3": ("c3", 19456, "f32", "C3: SILVER2 hexapod x 1024 envs"),
@@ -532,7 +533,7 @@ def main():
             "metric": "body-steps/sec", "value": value, "unit": "body-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "baseline_config": BASELINE_CONFIG.get(args.workload, "variant"),
                        "bodies_per_gpu": sc.n, "coefficients": coeff,
                        "scene_replicas_per_gpu": args.scenes, "bytes_per_body_step": bpb,

@@ -70,8 +70,7 @@ int64_t     hydro_capacity(const hydro_t *h);
 
 /* Scene scalars: water density and gravity ("globals", hydrodynamics_config.json:2-5;
  * ctor arguments water_density / gravity, numba_hydrodynamics_wrapper.py:9-10).  Doubles, as the
- * reference passes Python floats: 9.81 is not an fp32 number, and the buoyancy and drag terms that
- * cancel along z are evaluated in fp64 inside the kernels. */
+ * reference passes Python floats: 9.81 is not an fp32 number, and the kernels evaluate the model in fp64. */
 int hydro_set_scene(hydro_t *h, double water_density, double gravity);
 
 /* Which of the reference's two calculators the results follow where the two differ.  Default
@@ -95,7 +94,7 @@ int hydro_set_semantics(hydro_t *h, int semantics);
  * (numba_hydrodynamics_wrapper.py:9-32) plus the rigid-body mass used by the clamp
  * (hydrodynamics_behavior.py:172-173,222).  `params[f]` points at n floats; `on_device` says
  * where those arrays live.  _f16 stores the seven coefficients as IEEE half in HBM (config 5:
- * 130 B per body-step instead of 144); dims and mass stay fp32, arithmetic stays fp32. */
+ * 130 B per body-step instead of 144); dims and mass stay fp32; the arithmetic is fp64 either way. */
 int hydro_set_params_f32(hydro_t *h, int64_t n, const float *const params[HYDRO_PARAM_FIELDS], int on_device);
 int hydro_set_params_f16(hydro_t *h, int64_t n, const float *const params[HYDRO_PARAM_FIELDS], int on_device);
 
@@ -116,9 +115,9 @@ int hydro_set_prev_velocity(hydro_t *h, int64_t n, const float *const prev[HYDRO
  *                        of a ping-pong integrator): pure 144 B (fp32) / 130 B (fp16
  *                        coefficients) per body-step, nothing written but the wrench.
  * `dt` is a double, as the `delta_time` Python float the reference's callback receives
- * (hydrodynamics_behavior.py:138,200-202).  The arithmetic is fp32 with fp64 cores; a body whose net
- * force or torque cancels its terms more than 8x is re-evaluated in fp64 from the raw inputs
- * (DESIGN.md section 4), which is why 1/dt must not be rounded on the way in.
+ * (hydrodynamics_behavior.py:138,200-202).  Inputs and outputs are fp32 arrays; the arithmetic in between is
+ * fp64 (the type of the reference's Numba path), each result rounded to fp32 once - which is why neither the scene
+ * scalars nor 1/dt may be rounded on the way in.
  * `stream` is a hipStream_t; NULL is HIP's default (null) stream, as in any HIP API.  The
  * engine's private stream (used for its own copies) is available from hydro_stream(). */
 int hydro_step_wrench(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], double dt,

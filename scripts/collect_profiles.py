@@ -78,5 +78,30 @@ tr["c5:tiled"] = {
     "in_bench_event_us": {"unprofiled": bench["roofline"]["kernel_us"],
                           "under_kernel_trace": json.load(open(os.path.join(src, "bench_stats.json")))["roofline"]["kernel_us"]},
 }
+# second roofline object: 4 194 304 bodies, fp16 coefficients
+if os.path.isdir(os.path.join(src, "fetch4m")):
+    shutil.copy(one("stats4m/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_f16_4m_kernel_stats.csv"))
+
+    def med(sub, counter):
+        vals = []
+        with open(one(os.path.join(sub, "**", "*counter_collection.csv")), newline="") as f:
+            for r in csv.DictReader(f):
+                if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        return statistics.median(vals) * 1024.0
+    f4, w4 = med("fetch4m", "FETCH_SIZE"), med("write4m", "WRITE_SIZE")
+    b4 = json.load(open(os.path.join(src, "bench_stats4m.json")))
+    n4 = b4["config"]["bodies_per_gpu"]; t4 = (n4 + 63) // 64
+    exp4 = t4 * 64 * (11 * 4 + 6 * 4) + t4 * 1920
+    tr["f16_4m:tiled"] = {
+        "hbm_bytes_per_launch": 2.0 * f4 + w4, "fetch_size_bytes_raw": f4, "fetch_size_bytes_corrected": 2.0 * f4, "write_size_bytes": w4,
+        "expected_read_bytes": exp4, "expected_write_bytes": t4 * 64 * 24, "algorithmic_bytes": n4 * 130,
+        "in_bench_event_us": {"under_kernel_trace": b4["roofline"]["kernel_us"]},
+        "frac_of_8TBs_algorithmic": b4["roofline"]["frac"],
+        "source": f"python bench.py --bodies 4194304 --scenes 2 (fp16 coefficients, two rotating replicas = 1.1 GB); rocprofv3 --pmc FETCH_SIZE / "
+                  f"WRITE_SIZE in separate passes, FETCH x2 (gfx950; 2 x FETCH vs the known read bytes: {100.0 * (2.0 * f4 / exp4 - 1.0):+.2f}%); "
+                  f"profiles/{tag}_f16_4m_kernel_stats.csv",
+    }
 json.dump(tr, open(path, "w"), indent=1)
 print(json.dumps(tr["c5:tiled"], indent=1))
+print(json.dumps(tr.get("f16_4m:tiled"), indent=1))

@@ -1,12 +1,12 @@
 // gfx950 (MI355X / CDNA4) kernels and C ABI of libhydro.so - see include/hydro.h.
 //
-// Every kernel is elementwise per rigid body and HBM-bound (about 560 VALU instructions
-// against 136-144 B per body-step): no MFMA anywhere.  What matters is
+// Every kernel is elementwise per rigid body and HBM-bound (about 600 VALU instructions, two thirds of them fp64 -
+// hydro_body.h says why - against 122-144 B per body-step): no MFMA anywhere.  What matters is
 //   * layouts in which each wave-instruction reads one contiguous 256-B run of one field
 //     (plain SoA) and - better - in which the ~28 runs a wavefront needs form three contiguous
 //     records (tiled SoA, the native layout): DRAM pages are consumed whole;
 //   * all of a body's 28 loads issued before the first use, so a wave has its whole working
-//     set in flight at once (single-pass kernels, latency hidden by 6 waves per SIMD);
+//     set in flight at once (single-pass kernels, latency hidden by 4 waves per SIMD: ~125 VGPRs);
 //   * non-temporal accesses for scenes larger than the caches: every byte is touched once per step;
 //   * nothing re-read and nothing written but the wrench (24 B per body).
 // The array-of-structs entry points (the simulator's tensor layout) stage the transposition
@@ -19,7 +19,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
-#include <type_traits>
 
 #include "../../include/hydro.h"
 #include "hydro_body.h"
@@ -27,17 +26,13 @@
 namespace {
 
 constexpr int kBlock = 256;                // 4 waves of 64 lanes
+constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
 // Resident waves per SIMD the wrench kernels are compiled for (second argument of __launch_bounds__: on HIP that is
-// waves per SIMD).  The fp32 pass needs ~100 VGPRs, the rarely executed fp64 re-evaluation ~125-150; with the bound
-// at 4 (<= 128 VGPRs) whatever does not fit is spilled INSIDE the cold block (it is marked unlikely and laid out
-// after s_endpgm), never on the path every wave runs.
+// waves per SIMD).  The fp64 body needs ~125 VGPRs: 4 waves per SIMD (<= 128 VGPRs), measured as good as 5 and
+// better than 3 for these kernels.
 #ifndef HYDRO_MIN_WAVES
 #define HYDRO_MIN_WAVES 4
 #endif
-#ifndef HYDRO_TILED_REREAD
-#define HYDRO_TILED_REREAD 0        // A/B knob: 1 = the tiled wrench kernel re-reads a flagged body's records instead of keeping them
-#endif
-constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
 
 // --------------------------------------------------------------------------
 // vector load / store helpers: VEC consecutive bodies of one SoA field per lane
@@ -154,51 +149,31 @@ struct SoaArgs {
     const float* mass;
     float* out[HYDRO_WRENCH_FIELDS];
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
-    double inv_dt;                           // fp64: the fast pass rounds it, the fp64 re-evaluation does not
+    double inv_dt;                           // 1 / dt in fp64 (dt is a double through the C ABI)
     int warp;                                // HYDRO_SEM_WARP (uniform)
     int64_t n;
 };
 
-// One body from already-loaded scalars.  inv_dt arrives in fp64 (the fp64 re-evaluation of ill-conditioned bodies,
-// hydro_body.h wrench_fp64, takes the finite difference itself); the fast pass uses its fp32 rounding.
-__device__ __forceinline__ hydro::BodyIn make_body(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
-                                                   const float (&d)[3], const float (&c)[7], float inv_dt)
+// One body from already-loaded scalars.
+__device__ __forceinline__ hydro::BodyIn make_body(const float (&s)[HYDRO_STATE_FIELDS], const float (&d)[3], const float (&c)[7])
 {
     hydro::BodyIn b;
     b.px = s[0]; b.py = s[1]; b.pz = s[2];
     b.qx = s[3]; b.qy = s[4]; b.qz = s[5]; b.qw = s[6];
     b.vx = s[7]; b.vy = s[8]; b.vz = s[9];
     b.wx = s[10]; b.wy = s[11]; b.wz = s[12];
-    // A13: finite-difference acceleration (hydrodynamics_behavior.py:200-202)
-    b.ax = (s[7] - pv[0]) * inv_dt; b.ay = (s[8] - pv[1]) * inv_dt; b.az = (s[9] - pv[2]) * inv_dt;
-    b.bx = (s[10] - pv[3]) * inv_dt; b.by = (s[11] - pv[4]) * inv_dt; b.bz = (s[12] - pv[5]) * inv_dt;
-    b.pvx = pv[0]; b.pvy = pv[1]; b.pvz = pv[2]; b.pwx = pv[3]; b.pwy = pv[4]; b.pwz = pv[5];
     b.dimx = d[0]; b.dimy = d[1]; b.dimz = d[2];
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3];
     b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
     return b;
 }
 
-// The compiler must not satisfy the re-read of a body's record from the registers of the first read (the point of
-// re-reading is that those registers are free during the fp32 pass): an empty asm with a memory clobber makes the
-// second set of loads distinct from the first.
-__device__ __forceinline__ void forget_memory() { asm volatile("" ::: "memory"); }
-
-// `reload(s, pv, d, c, mass)` reads the body's inputs again (wave-uniformly rare: hydro_body.h solve_wrench).
-template <typename Reload>
+// A13 (finite-difference acceleration, hydrodynamics_behavior.py:200-202) + model + lever arms + sum + clamp
 __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STATE_FIELDS], const float (&pv)[HYDRO_PREV_FIELDS],
                                                      const float (&d)[3], const float (&c)[7], float mass,
-                                                     double rho, double g, double inv_dt, bool warp, Reload reload,
-                                                     float* k_lin = nullptr, float* k_ang = nullptr)
+                                                     double rho, double g, double inv_dt, bool warp)
 {
-    const float inv_dt32 = (float)inv_dt;
-    return hydro::solve_wrench(make_body(s, pv, d, c, inv_dt32), mass, rho, g, inv_dt, warp,
-                               [&](float& m2) {
-                                   float s2[HYDRO_STATE_FIELDS], pv2[HYDRO_PREV_FIELDS], d2[3], c2[7];
-                                   forget_memory();
-                                   reload(s2, pv2, d2, c2, m2);
-                                   return make_body(s2, pv2, d2, c2, inv_dt32);
-                               }, k_lin, k_ang);
+    return hydro::solve_wrench(make_body(s, d, c), pv, mass, rho, g, inv_dt, warp);
 }
 
 // --------------------------------------------------------------------------
@@ -239,20 +214,7 @@ __global__ void __launch_bounds__(BLOCK, VEC == 1 ? HYDRO_MIN_WAVES : 2) wrench_
         for (int f = 0; f < 3; ++f) d[f] = dm[f][j];
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = cf[f][j];
-        const uint32_t bj = base + j;
-        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, a.warp != 0,
-            [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
-                float t[1];
-#pragma unroll
-                for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { load_f32<1, false>(a.st[f], bj, t); s2[f] = t[0]; }
-#pragma unroll
-                for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) { load_f32<1, false>(a.pv[f], bj, t); p2[f] = t[0]; }
-#pragma unroll
-                for (int f = 0; f < 3; ++f) { load_f32<1, false>(a.dims[f], bj, t); d2[f] = t[0]; }
-#pragma unroll
-                for (int f = 0; f < 7; ++f) { load_coef<1, HALF, false>(a.coef[f], bj, t); c2[f] = t[0]; }
-                load_f32<1, false>(a.mass, bj, t); m2 = t[0];
-            });
+        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, a.warp != 0);
         out[0][j] = w.fx; out[1][j] = w.fy; out[2][j] = w.fz;
         out[3][j] = w.tx; out[4][j] = w.ty; out[5][j] = w.tz;
     }
@@ -285,7 +247,7 @@ struct TiledArgs {
     const float* prm;                          // engine-owned: [tiles][11][64] f32, or f16 record (below)
     float* out;       uint32_t out_stride;     // 6 fields
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
-    double inv_dt;                           // fp64: the fast pass rounds it, the fp64 re-evaluation does not
+    double inv_dt;                           // 1 / dt in fp64 (dt is a double through the C ABI)
     int warp;                                // HYDRO_SEM_WARP (uniform)
     uint32_t n;
 };
@@ -334,17 +296,7 @@ __global__ void __launch_bounds__(BLOCK, HYDRO_MIN_WAVES) wrench_tiled_kernel(co
     const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
     load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
-#if HYDRO_TILED_REREAD
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0,
-        [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
-            load_tile_records<HALF, false>(a, tile, lane, so, po, s2, p2, d2, c2, m2);
-        });
-#else
-    // this kernel keeps the inputs in registers for the fp64 pass: it fits 128 VGPRs (4 waves per SIMD) either way, and
-    // a re-read (an L2 / HBM round trip) makes the flagged wavefronts - whose length IS the tail of the launch - longer
-    const hydro::Wrench w = hydro::solve_wrench(make_body(s, pv, d, c, (float)a.inv_dt), mass, a.rho, a.g, a.inv_dt, a.warp != 0,
-                                                [&](float& m2) { m2 = mass; return make_body(s, pv, d, c, (float)a.inv_dt); });
-#endif
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
     const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
     stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
     stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
@@ -469,7 +421,7 @@ struct AosArgs {
     float* pv;              // engine-owned previous velocity, tiled [tiles][6][64] (read, then updated)
     const float* prm;       // engine-owned parameters, tiled record (f32 or fp16-coefficient form)
     double rho, g;                           // scene scalars stay fp64 up to the kernel (hydro_body.h)
-    double inv_dt;                           // fp64: the fast pass rounds it, the fp64 re-evaluation does not
+    double inv_dt;                           // 1 / dt in fp64 (dt is a double through the C ABI)
     int warp;                                // HYDRO_SEM_WARP (uniform)
     int64_t n;
 };
@@ -520,41 +472,33 @@ __global__ void __launch_bounds__(kBlock, HYDRO_MIN_WAVES) wrench_aos_kernel(con
     const uint32_t tile = ic >> 6, tl = ic & 63u;                  // w0 is a multiple of 64: tile == this wave's tile
     const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + tl) * 4u;
     // one body's inputs: position and velocity from the wave's LDS slice, orientation as one float4, previous
-    // velocity and parameters from the engine's tiled records (also the re-read of the fp64 pass: the slice still
-    // holds the inputs then - forces and torques go into it only after the last read)
-    auto gather = [&](auto nt, float (&s_)[HYDRO_STATE_FIELDS], float (&pv_)[HYDRO_PREV_FIELDS], float (&d_)[3], float (&c_)[7], float& m_) {
-        constexpr bool kNt = decltype(nt)::value;
-        s_[0] = lds_pos[3 * lc]; s_[1] = lds_pos[3 * lc + 1]; s_[2] = lds_pos[3 * lc + 2];
-        const f4 q = ldg<kNt>(reinterpret_cast<const f4*>(a.quat) + ic);
-        if (a.quat_xyzw) { s_[3] = q.x; s_[4] = q.y; s_[5] = q.z; s_[6] = q.w; }
-        else             { s_[3] = q.y; s_[4] = q.z; s_[5] = q.w; s_[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
+    // velocity and parameters from the engine's tiled records
+    s[0] = lds_pos[3 * lc]; s[1] = lds_pos[3 * lc + 1]; s[2] = lds_pos[3 * lc + 2];
+    const f4 q = ldg<NT>(reinterpret_cast<const f4*>(a.quat) + ic);
+    if (a.quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
+    else             { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
 #pragma unroll
-        for (int f = 0; f < 6; ++f) s_[7 + f] = lds[6 * lc + f];
+    for (int f = 0; f < 6; ++f) s[7 + f] = lds[6 * lc + f];
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv_[f] = ldg<kNt>(at<float>(a.pv, po, f * 256u));
-        if constexpr (HALF) {
-            const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + tl * 4u;
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
+    if constexpr (HALF) {
+        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + tl * 4u;
 #pragma unroll
-            for (int f = 0; f < 3; ++f) d_[f] = ldg<kNt>(at<float>(a.prm, qo, f * 256u));
-            m_ = ldg<kNt>(at<float>(a.prm, qo, 3 * 256u));
-            const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + tl * 2u;
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
+        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + tl * 2u;
 #pragma unroll
-            for (int f = 0; f < 7; ++f) c_[f] = half_bits_to_float(ldg<kNt>(at<unsigned short>(a.prm, ho, f * 128u)));
-        } else {
-            const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + tl * 4u;
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
+    } else {
+        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + tl * 4u;
 #pragma unroll
-            for (int f = 0; f < 3; ++f) d_[f] = ldg<kNt>(at<float>(a.prm, qo, f * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
 #pragma unroll
-            for (int f = 0; f < 7; ++f) c_[f] = ldg<kNt>(at<float>(a.prm, qo + (3 + f) * 256u));
-            m_ = ldg<kNt>(at<float>(a.prm, qo, 10 * 256u));
-        }
-    };
-    gather(std::integral_constant<bool, NT>{}, s, pv, d, c, mass);
+        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
+        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
+    }
 
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0,
-        [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
-            gather(std::false_type{}, s2, p2, d2, c2, m2);
-        });
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
 
     if (live) {
 #pragma unroll
@@ -602,25 +546,21 @@ __global__ void __launch_bounds__(kBlock) components_kernel(const CompArgs a)
     b.qx = a.st[3][i]; b.qy = a.st[4][i]; b.qz = a.st[5][i]; b.qw = a.st[6][i];
     b.vx = a.st[7][i]; b.vy = a.st[8][i]; b.vz = a.st[9][i];
     b.wx = a.st[10][i]; b.wy = a.st[11][i]; b.wz = a.st[12][i];
-    b.ax = a.acc[0][i]; b.ay = a.acc[1][i]; b.az = a.acc[2][i];
-    b.bx = a.acc[3][i]; b.by = a.acc[4][i]; b.bz = a.acc[5][i];
     b.dimx = a.dims[0][i]; b.dimy = a.dims[1][i]; b.dimz = a.dims[2][i];
     b.cd_lin = load_coef1<HALF>(a.coef[0], i); b.cd_ang = load_coef1<HALF>(a.coef[1], i);
     b.damp_lin = load_coef1<HALF>(a.coef[2], i); b.damp_ang = load_coef1<HALF>(a.coef[3], i);
     b.lift = load_coef1<HALF>(a.coef[4], i); b.am_lin = load_coef1<HALF>(a.coef[5], i);
     b.am_ang = load_coef1<HALF>(a.coef[6], i);
-    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g, a.warp != 0);
-    const float live = (o.wet || a.warp != 0) ? 1.0f : 0.0f;     // centres of a dry body: zeros (Numba) / position (Warp), N6
-    a.out[0][i] = 0.0f; a.out[1][i] = 0.0f; a.out[2][i] = o.buoy_z;
-    a.out[3][i] = o.drag_fx; a.out[4][i] = o.drag_fy; a.out[5][i] = o.drag_fz;
-    a.out[6][i] = o.lift_fx; a.out[7][i] = o.lift_fy; a.out[8][i] = o.lift_fz;
-    a.out[9][i] = o.drag_tx; a.out[10][i] = o.drag_ty; a.out[11][i] = o.drag_tz;
-    a.out[12][i] = o.am_fx; a.out[13][i] = o.am_fy; a.out[14][i] = o.am_fz;
-    a.out[15][i] = o.am_tx; a.out[16][i] = o.am_ty; a.out[17][i] = o.am_tz;
-    // world-space centres; zeros when dry (Numba semantics, numba_hydrodynamics.py:277-279)
-    a.out[18][i] = live * (b.px + o.armb_x); a.out[19][i] = live * (b.py + o.armb_y); a.out[20][i] = live * (b.pz + o.armb_z);
-    a.out[21][i] = live * (b.px + o.armp_x); a.out[22][i] = live * (b.py + o.armp_y); a.out[23][i] = live * (b.pz + o.armp_z);
-    if (a.ratio) a.ratio[i] = o.ratio;
+    const hydro::Body o = hydro::solve_body(b, a.acc[0][i], a.acc[1][i], a.acc[2][i], a.acc[3][i], a.acc[4][i], a.acc[5][i],
+                                            a.rho, a.g, a.warp != 0);
+    const hydro::Components c = hydro::round_components(o, b, a.warp != 0);
+    // reference order: buoyancy F, drag F, lift F, drag T, added-mass F, added-mass T, cob, cop (world space; zeros
+    // when dry - Numba semantics, numba_hydrodynamics.py:277-279)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) a.out[3 * k + x][i] = c.v[k][x];
+    if (a.ratio) a.ratio[i] = c.ratio;
 }
 
 // component mode on the calculator's own argument layout: six (n,3)/(n,4) tensors in, eight (n,3)
@@ -648,8 +588,6 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
     b.qx = a.quat_xyzw[4 * i]; b.qy = a.quat_xyzw[4 * i + 1]; b.qz = a.quat_xyzw[4 * i + 2]; b.qw = a.quat_xyzw[4 * i + 3];
     b.vx = a.lin_vel[3 * i]; b.vy = a.lin_vel[3 * i + 1]; b.vz = a.lin_vel[3 * i + 2];
     b.wx = a.ang_vel[3 * i]; b.wy = a.ang_vel[3 * i + 1]; b.wz = a.ang_vel[3 * i + 2];
-    b.ax = a.lin_acc[3 * i]; b.ay = a.lin_acc[3 * i + 1]; b.az = a.lin_acc[3 * i + 2];
-    b.bx = a.ang_acc[3 * i]; b.by = a.ang_acc[3 * i + 1]; b.bz = a.ang_acc[3 * i + 2];
     const uint32_t tile = i >> 6, lane = i & 63u;
     float c[7];
     if constexpr (HALF) {
@@ -665,17 +603,14 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
         for (int f = 0; f < 7; ++f) c[f] = *at<float>(a.prm, qo + (3 + f) * 256u);
     }
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3]; b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
-    const hydro::BodyOut o = hydro::solve_body(b, a.rho, a.g, a.warp != 0);
-    const float live = (o.wet || a.warp != 0) ? 1.0f : 0.0f;     // N6
-    const float v[8][3] = {{0.0f, 0.0f, o.buoy_z}, {o.drag_fx, o.drag_fy, o.drag_fz}, {o.lift_fx, o.lift_fy, o.lift_fz},
-                           {o.drag_tx, o.drag_ty, o.drag_tz}, {o.am_fx, o.am_fy, o.am_fz}, {o.am_tx, o.am_ty, o.am_tz},
-                           {live * (b.px + o.armb_x), live * (b.py + o.armb_y), live * (b.pz + o.armb_z)},
-                           {live * (b.px + o.armp_x), live * (b.py + o.armp_y), live * (b.pz + o.armp_z)}};
+    const hydro::Body o = hydro::solve_body(b, a.lin_acc[3 * i], a.lin_acc[3 * i + 1], a.lin_acc[3 * i + 2],
+                                            a.ang_acc[3 * i], a.ang_acc[3 * i + 1], a.ang_acc[3 * i + 2], a.rho, a.g, a.warp != 0);
+    const hydro::Components r = hydro::round_components(o, b, a.warp != 0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        a.out[k][3 * i] = v[k][0]; a.out[k][3 * i + 1] = v[k][1]; a.out[k][3 * i + 2] = v[k][2];
+        a.out[k][3 * i] = r.v[k][0]; a.out[k][3 * i + 1] = r.v[k][1]; a.out[k][3 * i + 2] = r.v[k][2];
     }
-    if (a.ratio) a.ratio[i] = o.ratio;
+    if (a.ratio) a.ratio[i] = r.ratio;
 }
 
 // --------------------------------------------------------------------------
@@ -874,12 +809,8 @@ __global__ void __launch_bounds__(kBlock, HYDRO_MIN_WAVES) step_fused_tiled_kern
     const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
     load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
-    float k_lin = 0.0f, k_ang = 0.0f;
-    // (the fp64 pass re-reads the records BEFORE anything is stored: state_out may alias the previous-velocity buffer)
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0,
-        [&](float (&s2)[HYDRO_STATE_FIELDS], float (&p2)[HYDRO_PREV_FIELDS], float (&d2)[3], float (&c2)[7], float& m2) {
-            load_tile_records<HALF, false>(a, tile, lane, so, po, s2, p2, d2, c2, m2);
-        }, IMPLICIT ? &k_lin : nullptr, IMPLICIT ? &k_ang : nullptr);
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+    const float k_lin = w.k_lin, k_ang = w.k_ang;     // used by the implicit form only
     const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
     float o[HYDRO_STATE_FIELDS];
     integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, k_lin, k_ang, o);

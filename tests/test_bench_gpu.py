@@ -23,7 +23,7 @@ def test_bench_json_contract(native_built):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["scaling"] == "weak"
-    assert d["unit"] == "body-steps/s" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["unit"] == "body-steps/s" and d["vs_baseline"] is None and d["dtype"] == "f64"
     assert "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"

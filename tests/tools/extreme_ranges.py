@@ -47,19 +47,14 @@ if __name__ == "__main__":
               f"|F| {np.linalg.norm(rf[i]):.3g} dF {np.linalg.norm(f[i] - rf[i]):.3g} |T| {np.linalg.norm(rt[i]):.3g} dT {np.linalg.norm(t[i] - rt[i]):.3g}")
     # component breakdown of the worst body
     i = int(np.argmax(err))
-    out = np.zeros(30, np.float32)
+    out = np.zeros(25, np.float32)
     lib.emul_body(state[i].ctypes.data_as(fp), prev[i].ctypes.data_as(fp), params[i].ctypes.data_as(fp), ctypes.c_double(1025.0), ctypes.c_double(9.81),
                   ctypes.c_double(dt), out.ctypes.data_as(fp))
     acc = ho.finite_difference_accel(state[i:i + 1].astype(np.float64), prev[i:i + 1].astype(np.float64), dt)
     comps, ratio = c_oracle.components(state[i:i + 1], acc, params[i:i + 1, :10], 1025.0, 9.81)
-    c = comps[0]; p = state[i, :3].astype(np.float64)
-    def cmp(name, a, b):
-        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-        print(f"  {name:10s} emul {a} ref {b} rel {np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300):.2e}")
+    c = comps[0]; v = out[:24].reshape(8, 3)
     print("worst body: q", state[i, 3:7], "v", state[i, 7:10], "w", state[i, 10:13], "ratio", ratio[0])
-    cmp("dragF", out[2:5], c[1]); cmp("liftF", out[5:8], c[2]); cmp("dragT", out[8:11], c[3]); cmp("amT", out[14:17], c[5])
-    cmp("armb", out[17:20], c[6] - p); cmp("armp", out[20:23], c[7] - p)
-    cmp("armb x B", [out[27], out[28], 0.0], np.cross(c[6] - p, c[0]))
-    cmp("dragarmT", out[23:26], np.cross(c[7] - p, c[1]))
-    cmp("liftarmT", np.cross(out[20:23].astype(np.float64), out[5:8].astype(np.float64)), np.cross(c[7] - p, c[2]))
+    for k, name in enumerate(("buoyF", "dragF", "liftF", "dragT", "amF", "amT", "cob", "cop")):
+        a_, b_ = v[k].astype(np.float64), c[k]
+        print(f"  {name:6s} emul {a_} ref {b_} rel {np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-300):.2e}")
     print("  netT ref", rt[i] , "dT", t[i] - rt[i])
