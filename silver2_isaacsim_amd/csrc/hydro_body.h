@@ -88,6 +88,24 @@ HYDRO_FN double sqrt64(double x)
 #endif
 }
 
+// single-instruction fp32 forms on the device (v_sqrt_f32 / v_rcp_f32, 1 ulp); plain libm on the host instantiation
+HYDRO_FN float fast_sqrt(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+HYDRO_FN float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 HYDRO_FN uint32_t high_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, sizeof u); return (uint32_t)(u >> 32); }
 // mask = (mask << 1) | signbit(z): one v_alignbit_b32 on the device (the sign of a double is bit 31 of its high dword)
 HYDRO_FN uint32_t shift_in_sign(uint32_t mask, double z)
@@ -148,13 +166,14 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     // ---- A1: rotation matrix (numba_hydrodynamics.py:14-49), the quaternion used as given (N7) ----
     const double qx = b.qx, qy = b.qy, qz = b.qz, qw = b.qw;
     const double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
-    const double xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
+    const double xx = qx * x2, yy = qy * y2, zz = qz * z2;
     const double sx = qw * x2, sy = qw * y2, sz = qw * z2;
-    const double r00 = 1.0 - (yy + zz), r01 = xy - sz, r02 = xz + sy;
-    const double r10 = xy + sz, r11 = 1.0 - (xx + zz), r12 = yz - sx;
-    const double r20 = xz - sy, r21 = yz + sx, r22 = 1.0 - (xx + yy);
+    const double r00 = 1.0 - (yy + zz), r01 = __builtin_fma(qx, y2, -sz), r02 = __builtin_fma(qx, z2, sy);
+    const double r10 = __builtin_fma(qx, y2, sz), r11 = 1.0 - (xx + zz), r12 = __builtin_fma(qy, z2, -sx);
+    const double r20 = __builtin_fma(qx, z2, -sy), r21 = __builtin_fma(qy, z2, sx), r22 = 1.0 - (xx + yy);
     const double dx = b.dimx, dy = b.dimy, dz = b.dimz;
-    const double hx = 0.5 * dx, hy = 0.5 * dy, hz = 0.5 * dz, vol = dx * dy * dz;
+    const double hx = 0.5 * dx, hy = 0.5 * dy, hz = 0.5 * dz;
+    const double axy_ = dx * dy, vol = axy_ * dz;          // face area of the z faces, volume
 
     // ---- A3: vertical extent, submersion ratio (:86-96) ----
     const double ex = hx * r20, ey = hy * r21, ez = hz * r22;
@@ -215,7 +234,7 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     const double fsx = (ux < 0.0) ? 1.0 : -1.0, fsy = (uy < 0.0) ? 1.0 : -1.0, fsz = (uz < 0.0) ? 1.0 : -1.0;
     const double fax = ((ux != 0.0) && (pz + fsx * ex < 0.0)) ? fabs(ux) * (dy * dz) : 0.0;
     const double fay = ((uy != 0.0) && (pz + fsy * ey < 0.0)) ? fabs(uy) * (dx * dz) : 0.0;
-    const double faz = ((uz != 0.0) && (pz + fsz * ez < 0.0)) ? fabs(uz) * (dx * dy) : 0.0;
+    const double faz = ((uz != 0.0) && (pz + fsz * ez < 0.0)) ? fabs(uz) * axy_ : 0.0;
     const double area = fax + fay + faz;
     const bool has_area = area > kAreaEps;
     const double inv_area = has_area ? rcp64(area) : 0.0;
@@ -276,8 +295,8 @@ struct Wrench {
     float k_lin, k_ang;             // clamped drag coefficients for the implicit integrator: drag_force = k_lin v, drag_torque = k_ang w
 };
 
-// A14-A15: lever-arm torques, sum, safety clamp (hydrodynamics_behavior.py:212-226), in fp64; the six results are
-// rounded to fp32 here and nowhere earlier.  A dry body gets exact zeros (A4: selects, not multiplies).
+// A14-A15: lever-arm torques, sum (fp64, rounded to fp32 here and nowhere earlier), safety clamp
+// (hydrodynamics_behavior.py:212-226).  A dry body gets exact zeros (A4: selects, not multiplies).
 HYDRO_FN Wrench assemble_wrench(const Body& o, float mass)
 {
     const double gx = o.drag_fx + o.lift_fx, gy = o.drag_fy + o.lift_fy, gz = o.drag_fz + o.lift_fz;   // act at the centre of pressure
@@ -286,12 +305,15 @@ HYDRO_FN Wrench assemble_wrench(const Body& o, float mass)
     const double tx = o.armb_y * o.buoy_z + (o.armp_y * gz - o.armp_z * gy) + o.drag_tx + o.am_tx;
     const double ty = -o.armb_x * o.buoy_z + (o.armp_z * gx - o.armp_x * gz) + o.drag_ty + o.am_ty;
     const double tz = (o.armp_x * gy - o.armp_y * gx) + o.drag_tz + o.am_tz;
-    const double scale = fmin(1.0, ((double)mass * kMaxAccel) * rcp64(sqrt64(fx * fx + fy * fy + fz * fz) + kClampEps));
+    // The clamp factor multiplies the finished sums - nothing cancels after it - so it is the one quantity evaluated
+    // in fp32 (v_sqrt_f32 / v_rcp_f32, 1 ulp each): ~2e-7 on the results of the bodies it applies to (scale < 1).
+    const float f_mag = fast_sqrt((float)(fx * fx + fy * fy + fz * fz));
+    const float scale = fminf(1.0f, (mass * (float)kMaxAccel) * fast_rcp(f_mag + (float)kClampEps));
     Wrench w;
-    w.fx = o.wet ? (float)(fx * scale) : 0.0f; w.fy = o.wet ? (float)(fy * scale) : 0.0f; w.fz = o.wet ? (float)(fz * scale) : 0.0f;
-    w.tx = o.wet ? (float)(tx * scale) : 0.0f; w.ty = o.wet ? (float)(ty * scale) : 0.0f; w.tz = o.wet ? (float)(tz * scale) : 0.0f;
-    w.k_lin = o.wet ? (float)(o.lin_k * scale) : 0.0f;
-    w.k_ang = o.wet ? (float)(o.ang_k * scale) : 0.0f;
+    w.fx = o.wet ? (float)fx * scale : 0.0f; w.fy = o.wet ? (float)fy * scale : 0.0f; w.fz = o.wet ? (float)fz * scale : 0.0f;
+    w.tx = o.wet ? (float)tx * scale : 0.0f; w.ty = o.wet ? (float)ty * scale : 0.0f; w.tz = o.wet ? (float)tz * scale : 0.0f;
+    w.k_lin = o.wet ? (float)o.lin_k * scale : 0.0f;
+    w.k_ang = o.wet ? (float)o.ang_k * scale : 0.0f;
     return w;
 }
 
