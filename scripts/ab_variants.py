@@ -49,7 +49,7 @@ for kind, n, coeff, sets in (("c5", 1048576, "f16", 4), ("c5", 1048576, "f32", 4
         nat.SIGNATURES.update(full)
         if not hasattr(nat._lib, "hydro_set_semantics"):
             HydroEngine.set_semantics = lambda self, *_a, **_k: None
-        reps[nm] = [bench.Replica(sc, coeff, dev, roll=7919 * k) for k in range(sets)]
+        reps[nm] = [bench.Replica(sc, coeff, dev, roll=7919 * k, layout=os.environ.get("HYDRO_AB_LAYOUT", "tiled")) for k in range(sets)]
         if opt:
             import re
             w = re.search(r"w(\d)", opt); b = re.search(r"b(\d+)", opt)

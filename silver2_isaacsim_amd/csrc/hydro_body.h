@@ -32,7 +32,7 @@
 //     differences (hydrodynamics_behavior.py:212-214), so p_x and p_y are never needed (nor loaded);
 //   * at most one face per axis opposes the flow, selected by sign(R^T v_hat);
 //   * sin(2*asin(d)) = 2 d sqrt((1-d)(1+d));
-//   * reciprocals and square roots are the fp32 hardware seeds + two Newton steps in fp64.
+//   * reciprocals and square roots are the fp32 hardware seeds + one Newton step in fp64 (1.4e-14).
 // N1 completion (speed <= 1e-6 -> area 0, CoP = CoB) as in oracle/hydro_oracle.py.
 //
 // This header is compiled for the device by hipcc and, for the CPU-side numerics study only (tests/host_emul), by the
@@ -60,17 +60,16 @@ constexpr double kAxisEps = 1e-6;       // :210
 constexpr double kMaxAccel = 500.0;     // hydrodynamics_behavior.py:221
 constexpr double kClampEps = 1e-6;      // hydrodynamics_behavior.py:224
 
-// fp64 reciprocal and square root: the fp32 hardware seeds (v_rcp_f32 / v_rsq_f32, 1 ulp) and two Newton steps in
-// fp64 (2^-23 -> 2^-46 -> below fp64 resolution) - 7 and 11 instructions where the IEEE-exact sequences the compiler
-// expands `/` and sqrt() to take ~15 and ~25.  Arguments are within fp32 range wherever the result is used (guarded
-// by the model's own 1e-6 thresholds); sqrt64 returns 0 below 1e-30.  Plain libm on the host instantiation.
+// fp64 reciprocal and square root: the fp32 hardware seeds (v_rcp_f32 / v_rsq_f32, 1 ulp = 2^-23) and ONE Newton step
+// in fp64, which squares the error: 1.4e-14 relative - five orders of magnitude below the fp32 rounding of the results,
+// so even a 1e5-fold cancellation downstream stays at 1e-9.  5 and 7 instructions where the IEEE-exact sequences the
+// compiler expands `/` and sqrt() to take ~15 and ~25.  Arguments are within fp32 range wherever the result is used
+// (guarded by the model's own 1e-6 thresholds); sqrt64 returns 0 below 1e-30.  Plain libm on the host instantiation.
 HYDRO_FN double rcp64(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double r = (double)__builtin_amdgcn_rcpf((float)x);
-    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-    return r;
+    const double r = (double)__builtin_amdgcn_rcpf((float)x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
 #else
     return 1.0 / x;
 #endif
@@ -78,11 +77,9 @@ HYDRO_FN double rcp64(double x)
 HYDRO_FN double sqrt64(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double r = (double)__builtin_amdgcn_rsqf((float)x), h = 0.5 * r;
-    double y = x * r;
-    y = __builtin_fma(__builtin_fma(-y, y, x), h, y);
-    y = __builtin_fma(__builtin_fma(-y, y, x), h, y);
-    return x > 1e-30 ? y : 0.0;
+    const double r = (double)__builtin_amdgcn_rsqf((float)x);
+    const double y = x * r;
+    return x > 1e-30 ? __builtin_fma(__builtin_fma(-y, y, x), 0.5 * r, y) : 0.0;
 #else
     return x > 1e-30 ? sqrt(x) : 0.0;
 #endif
@@ -238,10 +235,14 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     const double area = fax + fay + faz;
     const bool has_area = area > kAreaEps;
     const double inv_area = has_area ? rcp64(area) : 0.0;
-    const double lpx = fsx * hx * (fax * inv_area), lpy = fsy * hy * (fay * inv_area), lpz = fsz * hz * (faz * inv_area);
-    o.armp_x = has_area ? r00 * lpx + r01 * lpy + r02 * lpz : o.armb_x;                   // cop = cob (:115,140)
-    o.armp_y = has_area ? r10 * lpx + r11 * lpy + r12 * lpz : o.armb_y;
-    o.armp_z = has_area ? r20 * lpx + r21 * lpy + r22 * lpz : o.armb_z;
+    // body-frame CoP arm: sum of (face centre x its share of the area); without area cop = cob (:115,140).  The
+    // choice is made on the body-frame vector, so one rotation serves both cases.
+    const double lpx = has_area ? fsx * hx * (fax * inv_area) : lbx;
+    const double lpy = has_area ? fsy * hy * (fay * inv_area) : lby;
+    const double lpz = has_area ? fsz * hz * (faz * inv_area) : lbz;
+    o.armp_x = r00 * lpx + r01 * lpy + r02 * lpz;
+    o.armp_y = r10 * lpx + r11 * lpy + r12 * lpz;
+    o.armp_z = r20 * lpx + r21 * lpy + r22 * lpz;
 
     // ---- A8: hybrid drag (:146-182).  -(1/2 rho s^2 Cd A) v_hat = -(1/2 rho s Cd A) v, so both parts scale v ----
     const double half_rho = 0.5 * rho;

@@ -23,16 +23,18 @@
 #include "../../include/hydro.h"
 #include "hydro_body.h"
 
+#ifndef HYDRO_AB_LDS_WRENCH
+#define HYDRO_AB_LDS_WRENCH 0        // A/B knob, see wrench_tiled_kernel
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;                // 4 waves of 64 lanes
 constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
-// Resident waves per SIMD the wrench kernels are compiled for (second argument of __launch_bounds__: on HIP that is
-// waves per SIMD).  The fp64 body needs ~125 VGPRs: 4 waves per SIMD (<= 128 VGPRs), measured as good as 5 and
-// better than 3 for these kernels.
-#ifndef HYDRO_MIN_WAVES
-#define HYDRO_MIN_WAVES 4
-#endif
+// Occupancy: the fp64 body needs 116-132 VGPRs depending on the kernel around it, i.e. 4 waves per SIMD (<= 128) for the
+// tiled / array-of-structs kernels and 3 for the plain-SoA and fused ones.  Forcing 4 there (__launch_bounds__'
+// second argument) makes the compiler spill 2-4 registers on the path every wave runs: measured 28.2 vs 24.0 us at
+// 1 M bodies - the kernels are left at what they need.
 
 // --------------------------------------------------------------------------
 // vector load / store helpers: VEC consecutive bodies of one SoA field per lane
@@ -182,7 +184,7 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
 // with fp16 coefficients) parameters in, 24 B wrench out (+24 B if WRITE_PREV).
 // --------------------------------------------------------------------------
 template <int BLOCK, int VEC, bool HALF, bool WRITE_PREV, bool NT>
-__global__ void __launch_bounds__(BLOCK, VEC == 1 ? HYDRO_MIN_WAVES : 2) wrench_soa_kernel(const SoaArgs a)
+__global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
 {
     // Precondition (host side, launch_soa): a.n is a multiple of VEC; the <= VEC-1 leftover
     // bodies go to a second launch of the VEC=1 instance.  32-bit element offsets: the field
@@ -225,6 +227,17 @@ __global__ void __launch_bounds__(BLOCK, VEC == 1 ? HYDRO_MIN_WAVES : 2) wrench_
 #pragma unroll
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) store_f32<VEC, NT>(a.pv_out[f], base, st[7 + f]);
     }
+}
+
+// Wave-private staging: each wavefront transposes ITS 64 bodies through its own LDS slice (positions
+// 768 B, velocities 1536 B in; forces + torques 1536 B out), so no workgroup barrier is needed at all.
+// LDS operations of one wave execute in order; what has to be prevented is the COMPILER moving a lane's
+// reads above other lanes' writes (per thread the addresses differ), hence the wavefront-scope fences.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // --------------------------------------------------------------------------
@@ -286,7 +299,7 @@ __device__ __forceinline__ void load_tile_records(const TiledArgs& a, uint32_t t
 }
 
 template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT>
-__global__ void __launch_bounds__(BLOCK, HYDRO_MIN_WAVES) wrench_tiled_kernel(const TiledArgs a)
+__global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n) return;
@@ -297,9 +310,25 @@ __global__ void __launch_bounds__(BLOCK, HYDRO_MIN_WAVES) wrench_tiled_kernel(co
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
     load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
     const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+#if HYDRO_AB_LDS_WRENCH
+    // A/B knob ("LDS staging"): the wave's 6 x 256 B of wrench go through a wave-private LDS slice
+    // and leave as 1.5 sixteen-byte stores per lane instead of six four-byte ones.  Measured: no faster - the
+    // four-byte stores of a wave already cover whole 256-B runs.
+    {
+        __shared__ __attribute__((aligned(16))) float stage[BLOCK / 64][6 * 64];
+        using f4 = float __attribute__((ext_vector_type(4)));
+        float* sl = stage[threadIdx.x >> 6];
+        sl[lane] = w.fx; sl[64 + lane] = w.fy; sl[128 + lane] = w.fz; sl[192 + lane] = w.tx; sl[256 + lane] = w.ty; sl[320 + lane] = w.tz;
+        wave_lds_fence();
+        f4* dst = reinterpret_cast<f4*>(const_cast<float*>(a.out) + (size_t)__umul24(tile, a.out_stride));
+        stg<NT>(dst + lane, reinterpret_cast<const f4*>(sl)[lane]);
+        if (lane < 32u) stg<NT>(dst + 64 + lane, reinterpret_cast<const f4*>(sl)[64 + lane]);
+    }
+#else
     const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
     stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
     stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
+#endif
     if constexpr (WRITE_PREV) {
         const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
 #pragma unroll
@@ -426,19 +455,8 @@ struct AosArgs {
     int64_t n;
 };
 
-// Wave-private staging: each wavefront transposes ITS 64 bodies through its own LDS slice (positions
-// 768 B, velocities 1536 B in; forces + torques 1536 B out), so no workgroup barrier is needed at all.
-// LDS operations of one wave execute in order; what has to be prevented is the COMPILER moving a lane's
-// reads above other lanes' writes (per thread the addresses differ), hence the wavefront-scope fences.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <bool HALF, bool NT>
-__global__ void __launch_bounds__(kBlock, HYDRO_MIN_WAVES) wrench_aos_kernel(const AosArgs a)
+__global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
 {
     constexpr int kWaves = kBlock / 64;
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves][64 * 9];   // per wave: 6*64 vel | 3*64 pos  (2.25 KiB)
@@ -799,7 +817,7 @@ struct FusedArgs {
 };
 
 template <bool HALF, bool NT, bool IMPLICIT>
-__global__ void __launch_bounds__(kBlock, HYDRO_MIN_WAVES) step_fused_tiled_kernel(const FusedArgs fa)
+__global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArgs fa)
 {
     const TiledArgs& a = fa.t;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
