@@ -127,6 +127,9 @@ constexpr uint32_t lattice_mask(int axis, int value)
     return m;
 }
 
+// the bit of lattice point (i,j,k), i,j,k in {-1,0,1}
+constexpr uint32_t lattice_bit(int i, int j, int k) { return 1u << (26 - (9 * (i + 1) + 3 * (j + 1) + (k + 1))); }
+
 struct BodyIn {
     float px, py, pz;               // p_x, p_y are never read by the wrench (it does not depend on them)
     float qx, qy, qz, qw;           // unit quaternion xyzw, NOT normalised (N7)
@@ -229,9 +232,14 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     const double uy = r01 * nx + r11 * ny + r21 * nz;
     const double uz = r02 * nx + r12 * ny + r22 * nz;
     const double fsx = (ux < 0.0) ? 1.0 : -1.0, fsy = (uy < 0.0) ? 1.0 : -1.0, fsz = (uz < 0.0) ? 1.0 : -1.0;
-    const double fax = ((ux != 0.0) && (pz + fsx * ex < 0.0)) ? fabs(ux) * (dy * dz) : 0.0;
-    const double fay = ((uy != 0.0) && (pz + fsy * ey < 0.0)) ? fabs(uy) * (dx * dz) : 0.0;
-    const double faz = ((uz != 0.0) && (pz + fsz * ez < 0.0)) ? fabs(uz) * axy_ : 0.0;
+    // (the six face centres ARE lattice points - (+-1,0,0), (0,+-1,0), (0,0,+-1) - so "centre below the surface" is a
+    // bit of the keypoint mask: the same value p_z +- e_a, the same sign bit)
+    const bool wfx = wetmask & ((ux < 0.0) ? lattice_bit(1, 0, 0) : lattice_bit(-1, 0, 0));
+    const bool wfy = wetmask & ((uy < 0.0) ? lattice_bit(0, 1, 0) : lattice_bit(0, -1, 0));
+    const bool wfz = wetmask & ((uz < 0.0) ? lattice_bit(0, 0, 1) : lattice_bit(0, 0, -1));
+    const double fax = ((ux != 0.0) && wfx) ? fabs(ux) * (dy * dz) : 0.0;
+    const double fay = ((uy != 0.0) && wfy) ? fabs(uy) * (dx * dz) : 0.0;
+    const double faz = ((uz != 0.0) && wfz) ? fabs(uz) * axy_ : 0.0;
     const double area = fax + fay + faz;
     const bool has_area = area > kAreaEps;
     const double inv_area = has_area ? rcp64(area) : 0.0;
@@ -268,7 +276,8 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
         // C_L / |axis| from ONE reciprocal and ONE square root:  2 d sqrt((1-d)(1+d) / |axis|^2)
         const double cl_over_n = lift_on ? 2.0 * d * sqrt64(fmax(0.0, (1.0 - d) * (1.0 + d)) * rcp64(n2)) : 0.0;
         const double k = (half_rho * (speed * speed) * (area * (double)b.lift)) * (cl_over_n * ratio);
-        o.lift_fx = k * (axy * nz - axz * ny); o.lift_fy = k * (axz * nx - axx * nz); o.lift_fz = k * (axx * ny - axy * nx);
+        // axis x v_hat = up |v_hat|^2 - v_hat (v_hat . up) = up - u_z v_hat      (|v_hat|^2 = 1 to 1e-16)
+        o.lift_fx = k * __builtin_fma(-uz, nx, r02); o.lift_fy = k * __builtin_fma(-uz, ny, r12); o.lift_fz = k * __builtin_fma(-uz, nz, r22);
     }
 
     // ---- A10: added mass (:220-253; diagonal of numba_hydrodynamics_wrapper.py:101-112) ----
