@@ -40,7 +40,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
            # FMA contraction per source expression only (the HIP default, "fast", contracts across
            # statements and does so differently in each template instantiation): every kernel
            # variant, SoA or AoS, 1 or 2 bodies per lane, then returns the same bits for a body
-           "-ffp-contract=on"] + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
+           "-ffp-contract=on",
+           # kernarg preload (gfx950): the first 16 dwords of a kernel's scalar arguments arrive in SGPRs with the wave
+           # instead of behind scalar-memory loads; the hot kernels order their arguments for it (hydro_kernels.hip)
+           "-mllvm", "-amdgpu-kernarg-preload-count=16"] + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))

@@ -298,9 +298,18 @@ __device__ __forceinline__ void load_tile_records(const TiledArgs& a, uint32_t t
     }
 }
 
+// The arguments are passed as individual scalars, the ones every wave needs before it can issue its first load in
+// the first 16 dwords: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py) those arrive in SGPRs with the wave
+// (gfx950 kernarg preload) instead of behind three dependent scalar-memory round trips (~0.3 us per wave start,
+// exposed in the ramp of every launch and in all of a 2.6 us launch).  A struct passed by value cannot be preloaded.
 template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT>
-__global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const TiledArgs a)
+__global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
+                                                             uint32_t st_stride, uint32_t pv_stride, uint32_t out_stride, uint32_t pvo_stride,
+                                                             uint32_t n, int warp, double rho, double g, double inv_dt)
 {
+    TiledArgs a;
+    a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pv_out; a.pvo_stride = pvo_stride;
+    a.prm = k_prm; a.out = k_out; a.out_stride = out_stride; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = warp; a.n = n;
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n) return;
     const uint32_t tile = i >> 6, lane = i & 63u;
@@ -456,8 +465,13 @@ struct AosArgs {
 };
 
 template <bool HALF, bool NT>
-__global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const AosArgs a)
+__global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const float* k_pos, const float* k_quat, const float* k_vel, float* k_force, float* k_torque,
+                                                           float* k_pv, const float* k_prm, int quat_xyzw, uint32_t n32,      // 16 dwords: preloaded
+                                                           int warp, double rho, double g, double inv_dt)
 {
+    AosArgs a;                                  // (scalar arguments: see wrench_tiled_kernel)
+    a.pos = k_pos; a.quat = k_quat; a.quat_xyzw = quat_xyzw; a.vel = k_vel; a.force = k_force; a.torque = k_torque; a.pv = k_pv; a.prm = k_prm;
+    a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = warp; a.n = n32;
     constexpr int kWaves = kBlock / 64;
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves][64 * 9];   // per wave: 6*64 vel | 3*64 pos  (2.25 KiB)
     using f4 = float __attribute__((ext_vector_type(4)));
@@ -817,8 +831,14 @@ struct FusedArgs {
 };
 
 template <bool HALF, bool NT, bool IMPLICIT>
-__global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const FusedArgs fa)
+__global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_so, float* k_out,
+                                                                 uint32_t st_stride, uint32_t pv_stride, uint32_t so_stride, uint32_t out_stride,
+                                                                 uint32_t n, int warp, float dt, double rho, double g, double inv_dt)
 {
+    FusedArgs fa;                               // (scalar arguments: see wrench_tiled_kernel)
+    fa.t.st = k_st; fa.t.st_stride = st_stride; fa.t.pv = k_pv; fa.t.pv_stride = pv_stride; fa.t.pv_out = nullptr; fa.t.pvo_stride = 0;
+    fa.t.prm = k_prm; fa.t.out = k_out; fa.t.out_stride = out_stride; fa.t.rho = rho; fa.t.g = g; fa.t.inv_dt = inv_dt; fa.t.warp = warp; fa.t.n = n;
+    fa.so = k_so; fa.so_stride = so_stride; fa.dt = dt;
     const TiledArgs& a = fa.t;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -1306,7 +1326,8 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
         lds = blocks_per_cu > 0 ? ((size_t)160 * 1024 / (size_t)blocks_per_cu) & ~(size_t)255 : 0;
         if (lds > 64 * 1024) lds = 64 * 1024;                               // per-block LDS limit
     }
-#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, lds, s, a)
+#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, lds, s, \
+        a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt)
 #define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
 #define HYDRO_TILED_WP(BLOCK, HALF) do { if (own_prev) HYDRO_TILED_NT(BLOCK, HALF, true); else HYDRO_TILED_NT(BLOCK, HALF, false); } while (0)
 #define HYDRO_TILED_HALF(BLOCK) do { if (h->half_coeffs) HYDRO_TILED_WP(BLOCK, true); else HYDRO_TILED_WP(BLOCK, false); } while (0)
@@ -1369,11 +1390,13 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
-#define HYDRO_FUSED(HALF, NT) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true>), grid, blk, 0, s, fa); \
-                                   else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false>), grid, blk, 0, s, fa); } while (0)
+#define HYDRO_FUSED_ARGS a.st, a.pv, a.prm, fa.so, a.out, a.st_stride, a.pv_stride, fa.so_stride, a.out_stride, a.n, a.warp, fa.dt, a.rho, a.g, a.inv_dt
+#define HYDRO_FUSED(HALF, NT) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true>), grid, blk, 0, s, HYDRO_FUSED_ARGS); \
+                                   else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false>), grid, blk, 0, s, HYDRO_FUSED_ARGS); } while (0)
     if (h->half_coeffs) { if (nt) HYDRO_FUSED(true, true); else HYDRO_FUSED(true, false); }
     else { if (nt) HYDRO_FUSED(false, true); else HYDRO_FUSED(false, false); }
 #undef HYDRO_FUSED
+#undef HYDRO_FUSED_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
@@ -1451,13 +1474,15 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     if ((rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const int grid = grid_for(n, kBlock);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
+#define HYDRO_AOS_ARGS a.pos, a.quat, a.vel, a.force, a.torque, a.pv, a.prm, a.quat_xyzw, (uint32_t)a.n, a.warp, a.rho, a.g, a.inv_dt
     if (h->half_coeffs) {
-        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((wrench_aos_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, a);
+        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
+        else hipLaunchKernelGGL((wrench_aos_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
     } else {
-        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((wrench_aos_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, a);
+        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
+        else hipLaunchKernelGGL((wrench_aos_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
     }
+#undef HYDRO_AOS_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }

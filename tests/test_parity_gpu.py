@@ -53,6 +53,24 @@ def test_fused_wrench_matches_oracle_on_fixtures(name, vec, native_built):
     assert np.all(f[dry] == 0.0) and np.all(t[dry] == 0.0)
 
 
+@pytest.mark.parametrize("dt", [1.0 / 60.0, 1.0 / 120.0, 0.004999999999999999])
+def test_dt_is_a_double_through_the_abi(dt, native_built):
+    """The reference's callback receives `delta_time` as a Python float and divides by it in float64
+    (hydrodynamics_behavior.py:138,200-202).  1/60 is not an fp32 number: rounded to fp32 it is 5e-8 off, which an
+    added-mass-dominated body shows in full.  The C ABI takes dt as a double; results follow the oracle evaluated
+    with the SAME double to fp32 rounding, and differ from those of the fp32-rounded step."""
+    sc = scenes.scene_c2()
+    params = sc.params.copy()
+    params[:, 8] *= 20.0; params[:, 9] *= 20.0                       # added mass dominates the wrench
+    f, t = run_ext(sc.state, sc.prev, params, sc.rho, sc.g, dt)
+    rf, rt, _ = ho.step_wrench(sc.state, sc.prev, params, sc.rho, sc.g, dt)
+    err = ho.wrench_error(f, t, rf, rt, params, sc.rho, sc.g)
+    assert err.max() <= 3e-7, err.max()
+    rf32, rt32, _ = ho.step_wrench(sc.state, sc.prev, params, sc.rho, sc.g, float(np.float32(dt)))
+    err32 = ho.wrench_error(f, t, rf32, rt32, params, sc.rho, sc.g)
+    assert err32.max() > err.max()                                   # the rounded step is a different (worse) answer
+
+
 @pytest.mark.parametrize("name,builder", [("C2", scenes.scene_c2), ("C3", scenes.scene_c3)])
 def test_full_config_gate(name, builder, native_built):
     """Configs 2 and 3 in full (4 096 buoys; 19 x 1 024 hexapod links): gate 1e-5 on every body."""
