@@ -6,7 +6,7 @@
 //     (plain SoA) and - better - in which the ~28 runs a wavefront needs form three contiguous
 //     records (tiled SoA, the native layout): DRAM pages are consumed whole;
 //   * all of a body's 28 loads issued before the first use, so a wave has its whole working
-//     set in flight at once (single-pass kernels, latency hidden by 4 waves per SIMD: ~125 VGPRs);
+//     set in flight at once (single-pass kernels, latency hidden by 4 waves per SIMD: ~100 VGPRs);
 //   * non-temporal accesses for scenes larger than the caches: every byte is touched once per step;
 //   * nothing re-read and nothing written but the wrench (24 B per body).
 // The array-of-structs entry points (the simulator's tensor layout) stage the transposition
@@ -31,10 +31,10 @@ namespace {
 
 constexpr int kBlock = 256;                // 4 waves of 64 lanes
 constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
-// Occupancy: the fp64 body needs 116-132 VGPRs depending on the kernel around it, i.e. 4 waves per SIMD (<= 128) for the
-// tiled / array-of-structs kernels and 3 for the plain-SoA and fused ones.  Forcing 4 there (__launch_bounds__'
-// second argument) makes the compiler spill 2-4 registers on the path every wave runs: measured 28.2 vs 24.0 us at
-// 1 M bodies - the kernels are left at what they need.
+// Occupancy: the fp64 body needs 98-132 VGPRs depending on the kernel around it and on the build flags, i.e. 3-4 waves
+// per SIMD.  Forcing a number (__launch_bounds__' second argument) made the compiler spill 2-4 registers on the path
+// every wave runs when the kernel needed 130: measured 28.2 vs 24.0 us at 1 M bodies - the
+// kernels are left at what they need.
 
 // --------------------------------------------------------------------------
 // vector load / store helpers: VEC consecutive bodies of one SoA field per lane
