@@ -136,8 +136,6 @@ __device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t
     else return *at<float>(p, i * 4u);
 }
 
-__device__ __forceinline__ float ld1(const float* __restrict__ p, uint32_t i) { return *at<float>(p, i * 4u); }
-__device__ __forceinline__ void st1(float* __restrict__ p, uint32_t i, float v) { *at<float>(p, i * 4u) = v; }
 
 // --------------------------------------------------------------------------
 // kernel arguments (passed by value in the kernarg segment: pointers land in SGPRs)

@@ -148,3 +148,36 @@ def test_checkpoint_resume_is_bit_exact(native_built):
     got = c.state()
     c.close()
     assert np.array_equal(got, want)
+
+
+def test_kinetic_energy_monitor_in_the_closed_loop(native_built):
+    """SURVEY.md 8e on one GPU: every 64 steps (= one graph replay) the shard's kinetic energy is reduced on device on
+    the step stream and carried to the host on a side stream; the step loop never waits for it.  The samples equal an
+    fp64 host sum over the state at those steps, and the run's bits do not depend on the monitor being there."""
+    sc = scenes.scene_c2(n=3000)
+    plain, watched = ClosedLoopSim(sc), ClosedLoopSim(sc, ke_every=64)
+    ref = ClosedLoopSim(sc)
+    expect = []
+    for _ in range(4):
+        ref.run(64, graph_steps=64)
+        st = ref.state().astype(np.float64)
+        m = sc.params[:, 10].astype(np.float64)
+        expect.append(float((0.5 * m * (st[:, 7:10] ** 2).sum(1)).sum()))
+    plain.run(256, graph_steps=64)
+    watched.run(256, graph_steps=64)
+    watched.synchronize()
+    got = watched.monitor.collect(block=True)
+    assert [s for s, _ in watched.monitor.samples] == [64, 128, 192, 256] and len(got) <= 4
+    for (step, ke), want in zip(watched.monitor.samples, expect):
+        assert ke[0] == pytest.approx(want, rel=1e-12), step
+        assert ke[1] > 0.0                                            # rotational part (box inertia)
+    assert np.array_equal(plain.state(), watched.state())
+    # eager stepping samples at the same steps
+    eager = ClosedLoopSim(sc, ke_every=64)
+    eager.run_eager(130)
+    eager.synchronize()
+    eager.monitor.collect(block=True)
+    assert [s for s, _ in eager.monitor.samples] == [64, 128]
+    assert eager.monitor.samples[0][1][0] == pytest.approx(expect[0], rel=1e-12)
+    for s in (plain, watched, ref, eager):
+        s.close()
