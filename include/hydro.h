@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-/* 0.2.0: scene scalars are doubles (hydro_set_scene), hydro_set_semantics, waves_per_simd in hydro_set_tuning */
+/* 0.2.0: scene scalars are doubles (hydro_set_scene), hydro_set_semantics, waves_per_simd in hydro_set_tuning
+ * 0.3.0: dt is a double in every step / integrate entry point; the model is evaluated in fp64 */
 #define HYDRO_VERSION 0x000300
 
 #define HYDRO_OK         0
