@@ -2,6 +2,7 @@
 """CPU-only parity soak of the kernel arithmetic: csrc/hydro_body.h compiled for the host (tests/host_emul)
 against the fp64 C oracle, margin-gated and ungated C4 / C5 populations, many seeds, several processes.
     python tests/tools/host_soak.py FIRST_SEED N_SEEDS [n=262144] [workers=4] [gated|ungated|both]
+    HYDRO_SOAK_LAWS=c2,c3 picks the buoy / SILVER2-link laws (up to 65 536 bodies each) instead of c4,c5
 Prints every (seed, law, body) above 3e-6 and the error histogram; writes gpurun_out/host_soak.json."""
 import ctypes, json, os, sys, time
 from concurrent.futures import ProcessPoolExecutor
@@ -17,7 +18,12 @@ def one(args):
     from oracle import c_oracle, hydro_oracle as ho
     from silver2_isaacsim_amd import scenes
     lib = ctypes.CDLL(os.environ.get("HYDRO_EMUL", os.path.join(REPO, "tests", "host_emul", "libemul.so")))
-    sc = (scenes.scene_c4 if law == "c4" else scenes.scene_c5)(n=n, seed=seed, margin=1e-4 if gated else None)
+    if law == "c2":
+        sc = scenes.scene_c2(n=min(n, 65536), seed=seed, margin=1e-4 if gated else None)
+    elif law == "c3":
+        sc = scenes.scene_c3(envs=min(n, 65536) // 19, seed=seed, margin=1e-4 if gated else None)
+    else:
+        sc = (scenes.scene_c4 if law == "c4" else scenes.scene_c5)(n=n, seed=seed, margin=1e-4 if gated else None)
     st = np.ascontiguousarray(sc.state, np.float32); pv = np.ascontiguousarray(sc.prev, np.float32)
     pr = np.ascontiguousarray(sc.params, np.float32)
     f = np.empty((sc.n, 3), np.float32); t = np.empty((sc.n, 3), np.float32); r = np.empty(sc.n, np.float32)
@@ -39,7 +45,8 @@ if __name__ == "__main__":
     which = sys.argv[5] if len(sys.argv) > 5 else "gated"
     modes = {"gated": [True], "ungated": [False], "both": [True, False]}[which]
     seeds = [int(x) for x in os.environ["HYDRO_SOAK_SEEDS"].split(",")] if os.environ.get("HYDRO_SOAK_SEEDS") else range(first, first + count)
-    jobs = [(s, law, g, n) for s in seeds for law in ("c4", "c5") for g in modes]
+    laws = os.environ.get("HYDRO_SOAK_LAWS", "c4,c5").split(",")
+    jobs = [(s, law, g, n) for s in seeds for law in laws for g in modes]
     hist = {True: np.zeros(len(EDGES) - 1, int), False: np.zeros(len(EDGES) - 1, int)}
     worst, over, runs, t0, refined = {True: 0.0, False: 0.0}, {True: [], False: []}, [], time.time(), 0
     with ProcessPoolExecutor(workers) as ex:
