@@ -70,8 +70,8 @@ def near_upright_floaters(n=4096, seed=12, tilt_deg=0.5):
 def torque_balance(n=4096, seed=15, cancel=300.0):
     """Submerged and part-submerged bodies spinning at (1 +- 1/cancel) times the rate at which the angular drag
     torque equals the sum of the other torque terms (buoyancy arm, drag arm, lift arm): the net torque is a
-    `cancel`-fold cancellation of terms that an fp32 evaluation delivers to 1-2e-7 each.  These are the bodies
-    that take the fp64 re-evaluation (hydro_body.h wrench_fp64)."""
+    `cancel`-fold cancellation of terms that an fp32 evaluation delivers to 1-2e-7 each: the population that no
+    fp32 formulation of the model can pass, and the reason the kernels evaluate it in fp64."""
     rng = np.random.default_rng(seed)
     dims = np.exp(rng.uniform(np.log(0.1), np.log(2.0), (n, 3)))
     q = scenes.random_unit_quats(rng, n)

@@ -1,13 +1,12 @@
-"""Designed cancellation cases (tests/populations.py) against the fp64 oracle, gate 1e-5.
+"""Designed cancellation cases (tests/populations.py) against the fp64 oracle, gate 1e-5 - and, since the
+kernels evaluate the model in fp64, a much tighter bound: 5e-7 on every body.
 
-* terminal rise: drag along z cancels buoyancy 100x and 300x.  Needs buoyancy + z-drag summed in fp64 AND the
-  scene scalars handed over as doubles (g = 9.81 rounded to fp32 is already 4e-8 off).  The all-fp32 form this
-  repo started the round with: max 2.2e-5 / 2.5e-5, 8 / 22 of 4 096 bodies over the gate; now max 1.7e-6.
+* terminal rise: drag along z cancels buoyancy 100x and 300x (round 1's all-fp32 form: max 2.2e-5 / 2.5e-5; its fp64
+  islands: 1.7e-6).  Also needs the scene scalars as doubles: g = 9.81 rounded to fp32 is already 4e-8 off.
 * near-upright floaters (the buoy scenes): at rest the whole torque is the horizontal buoyancy lever arm, 1 %
-  (0.1 %) of its length at 0.5 (0.05) degrees of tilt.  Benign for both forms (3.9e-7 -> 1.9e-7): the wet lattice
-  is symmetric, so the arm is a single product; kept as the physical sanity case of the buoyancy torque.
+  (0.1 %) of its length at 0.5 (0.05) degrees of tilt - the case that needs the lattice mean itself in fp64.
 * torque balance: the angular drag torque cancels the lever-arm torques 300x / 3000x.  fp32 terms (1-2e-7 each) cannot
-  deliver 1e-5 of such a sum: these bodies are flagged by assemble_wrench and re-evaluated in fp64 (round 2)."""
+  deliver 1e-5 of such a sum whatever their formulation - the reason the whole body is fp64."""
 import ctypes
 import os
 
@@ -30,12 +29,12 @@ CASES = [("terminal_rise_100x", lambda: pop.terminal_rise(cancel=100.0)),
 def _check(name, f, t, state, prev, params):
     rf, rt, aux = ho.step_wrench(state, prev, params, pop.RHO, pop.G, pop.DT)
     err = ho.wrench_error(f, t, rf, rt, params, pop.RHO, pop.G)
-    assert err.max() <= GATE, f"{name}: max {err.max():.3e}"
+    assert err.max() <= 5e-7, f"{name}: max {err.max():.3e}"
     if name.startswith("terminal"):
         b = aux["buoyancy_force"][:, 2]
         cancel = b / np.maximum(np.abs(rf[:, 2] / aux["scale"]), 1e-300)
         assert np.median(cancel) > 50.0                               # the population is what it claims to be
-        assert np.median(err) < 2e-6
+        assert np.median(err) < 1e-7
     elif name.startswith("torque"):
         p = state[:, 0:3].astype(np.float64)
         parts = (np.cross(aux["center_of_buoyancy"] - p, aux["buoyancy_force"]), aux["drag_torque"],
@@ -43,7 +42,7 @@ def _check(name, f, t, state, prev, params):
         net = np.maximum(np.linalg.norm(rt / aux["scale"][:, None], axis=1), 1e-300)
         assert np.median(sum(np.linalg.norm(x, axis=1) for x in parts) / net) > 100.0
     else:
-        assert np.median(err) < 1e-6
+        assert np.median(err) < 1e-7
     return err
 
 
@@ -97,14 +96,15 @@ def _stress_population(n=65536, seed=1):
 
 def _check_stress(f, t, state, prev, params, dt):
     """dims 1e-3..30 m, speeds and spins 1e-5..50, depths to 1e4 m, accelerations to 1e4: everything finite, the
-    bulk at fp32 resolution, every body inside 1e-5.  (At 20-40 m/s the lift-arm torque can cancel the drag-arm
-    torque 80-100x with both good to 1.2-1.8e-7: round 1 had about one body in 3e5 at 1.1-1.9e-5 here; those
-    bodies now take the fp64 re-evaluation.  tests/tools/extreme_ranges.py prints the breakdown.)"""
+    99.9 % of the bodies at fp32 resolution, every body inside 1e-5.  What is left above 1e-6 (about one body in 1e4,
+    max 8e-6) is the REFERENCE's rounding, not the kernels': millimetre-sized bodies at 10+ m/s whose drag-arm torque
+    cancels 1e5-fold, while the reference forms world-space centres first (cop - p with |p| up to 1e4 m costs it
+    1e-12 m of a 1e-3 m arm = 1e-9, times the cancellation).  The kernels keep the arms body-relative and are the more
+    accurate side of that comparison.  (Round 1's fp32 terms had about one body in 3e5 above 1e-5 here.)"""
     assert np.isfinite(f).all() and np.isfinite(t).all()
     rf, rt, _ = ho.step_wrench(state, prev, params, pop.RHO, pop.G, dt)
     err = ho.wrench_error(f, t, rf, rt, params, pop.RHO, pop.G)
-    assert np.median(err) < 2e-7 and np.percentile(err, 99.99) < 5e-6
-    assert (err > GATE).sum() == 0, f"max {err.max():.3e}"
+    assert np.median(err) < 1e-7 and np.percentile(err, 99.9) < 5e-7 and err.max() <= GATE, f"max {err.max():.3e}"
 
 
 def test_stress_ranges_host_arithmetic(native_built):

@@ -45,19 +45,20 @@ def test_fp32_arithmetic_within_gate_on_fixtures(name, emul):
     assert np.all(f[dry] == 0.0) and np.all(t[dry] == 0.0)       # exact zeros, not small numbers
 
 
-def test_fp32_arithmetic_ungated_population(emul):
-    """No branch-margin rule: 65 536 bodies straight from the C4 law."""
+def test_ungated_population(emul):
+    """No branch-margin rule: 65 536 bodies straight from the C4 law.  The keypoint and face tests are taken on fp64
+    heights, like the reference's, so bodies with a keypoint on the waterline within fp32 resolution no longer flip."""
     from silver2_isaacsim_amd import scenes
     sc = scenes.scene_c4(n=65536, seed=2024, margin=None)
     f, t, _ = emul(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     rf, rt, _ = ho.step_wrench(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)
-    assert np.percentile(err, 99.9) < 2e-6
-    assert (err > GATE).sum() <= 2          # a keypoint within ~1e-7 L of the surface may flip
+    assert err.max() <= 5e-7
 
 
 def test_barely_wet_bodies_are_well_conditioned(emul):
-    """ratio in [1e-6, 1e-2]: z_min = p_z - extent cancels; fp64 extent keeps the error at fp32 eps."""
+    """ratio in [1e-6, 1e-2]: z_min = p_z - extent cancels catastrophically in fp32 (1e-2 at ratio 1e-5); in fp64 it
+    is exact to the final rounding."""
     from silver2_isaacsim_amd import scenes
     rng = np.random.default_rng(7)
     sc = scenes.scene_c4(n=8192, seed=31)
@@ -68,9 +69,9 @@ def test_barely_wet_bodies_are_well_conditioned(emul):
     rf, rt, aux = ho.step_wrench(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     wet = aux["ratio"] > 0
     rel = np.abs(r[wet] - aux["ratio"][wet]) / aux["ratio"][wet]
-    assert rel.max() < 1e-6
+    assert rel.max() < 1.2e-7
     fz = np.abs(f[wet, 2] - rf[wet, 2]) / np.maximum(np.abs(rf[wet, 2]), 1e-30)
-    assert np.median(fz) < 1e-6
+    assert np.median(fz) < 1e-7
 
 
 def test_large_world_offsets_do_not_hurt(emul):
@@ -86,8 +87,8 @@ def test_large_world_offsets_do_not_hurt(emul):
 
 @pytest.mark.parametrize("scale", [1.0 + 1e-5, 1.001, 1.02, 0.9])
 def test_non_unit_quaternions_host(scale, emul):
-    """The identities R R^T = (1+2e) I - e (R + R^T), |up|^2 - 1 = 2e(1 - R22) make the fp32 forms
-    exact in e = |q|^2 - 1: the reference uses the quaternion as given (N7)."""
+    """The reference uses the quaternion as given (N7): with e = |q|^2 - 1 its matrix is not orthogonal, and terms that
+    vanish for a rotation carry e.  The fp64 evaluation follows the same polynomial in q, so parity holds for any |q|."""
     from silver2_isaacsim_amd import scenes
     sc = scenes.scene_c4(n=16384, seed=21)
     st = sc.state.copy()
@@ -98,7 +99,7 @@ def test_non_unit_quaternions_host(scale, emul):
     f, t, _ = emul(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     rf, rt, _ = ho.step_wrench(st, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     err = ho.wrench_error(f, t, rf, rt, sc.params, sc.rho, sc.g)[keep]
-    assert np.percentile(err, 99.9) < 3e-6 and (err > 2.5e-5).sum() == 0
+    assert err.max() <= 5e-7
 
 
 def test_degenerate_inputs_host(emul):
