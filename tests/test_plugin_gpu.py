@@ -236,3 +236,53 @@ def test_calculator_is_one_launch_and_matches_the_soa_component_entry(native_bui
     torch.cuda.synchronize()
     print(f"calculate_hydrodynamic_forces, N=1: {(time.perf_counter() - t0) / 2000 * 1e6:.1f} us per call")
     w1.close()
+
+
+def test_prepared_aos_step_and_view_pointer_changes(native_built):
+    """engine.prepare_step_wrench_aos == step_wrench_aos bit for bit; the plugin's stepper re-prepares when the view
+    hands out different buffers, converts what is not float32 / contiguous / on the device, and gives the same wrench
+    either way (hydrodynamics_behavior.py:178-194: whatever the tensor API returns is used as it comes)."""
+    from silver2_isaacsim_amd.behavior import _AosStepper
+    from silver2_isaacsim_amd.engine import HydroEngine
+    fx = load_golden("c4")
+    n, dt = 500, float(fx["dt"])
+    dev = torch.device("cuda:0")
+    st = fx["state"][:n]
+    pos = torch.from_numpy(np.ascontiguousarray(st[:, 0:3])).to(dev)
+    quat = torch.from_numpy(np.ascontiguousarray(st[:, [6, 3, 4, 5]])).to(dev)
+    vel = torch.from_numpy(np.ascontiguousarray(st[:, 7:13])).to(dev)
+
+    def engine():
+        e = HydroEngine(n, dev, float(fx["rho"]), float(fx["g"]))
+        e.set_params(fx["params"][:n]); e.set_prev_velocity(fx["prev"][:n])
+        return e
+    a, b, c = engine(), engine(), engine()
+    F0, T0 = a.step_wrench_aos(pos, quat, vel, dt)
+    step = b.prepare_step_wrench_aos(pos, quat, vel)
+    F1, T1 = step(dt)
+    torch.cuda.synchronize()
+    assert torch.equal(F0, F1) and torch.equal(T0, T1)
+    with pytest.raises(ValueError):
+        b.prepare_step_wrench_aos(pos.double(), quat, vel)
+    # the plugin's stepper: float64 CPU tensors (converted every step, never cached), then device buffers (prepared once)
+    F = torch.empty((n, 3), device=dev); T = torch.empty((n, 3), device=dev)
+    stepper = _AosStepper(c, F, T)
+    used = stepper(pos.cpu().double(), quat.cpu().double(), vel.cpu().double(), dt)
+    torch.cuda.synchronize()
+    assert used.device == dev and used.dtype == torch.float32 and stepper._key is None
+    assert torch.equal(F, F0) and torch.equal(T, T0)
+    c.set_prev_velocity(fx["prev"][:n])
+    assert stepper(pos, quat, vel, dt) is pos and stepper._key is not None
+    prepared = stepper._step
+    c.set_prev_velocity(fx["prev"][:n])
+    stepper(pos, quat, vel, dt)
+    assert stepper._step is prepared                               # same buffers: no new preparation
+    pos2 = pos.clone()
+    c.set_prev_velocity(fx["prev"][:n])
+    stepper(pos2, quat, vel, dt)
+    torch.cuda.synchronize()
+    assert stepper._step is not prepared and torch.equal(F, F0) and torch.equal(T, T0)
+    for e in (a, b, c):
+        e.close()
+    with pytest.raises(Exception):
+        step(dt)                                                   # the engine behind a prepared call is gone
