@@ -471,6 +471,48 @@ def plugin_rate(batched: bool = True, steps: int = 2000):
             "apply_calls": world.apply_calls, "host": "silver2_isaacsim_amd.testing.FakeHost (in-memory; Isaac Sim cannot run on this box)"}
 
 
+def measure_traffic_live(timeout_s: float = 150.0):
+    """HBM bytes per launch of the headline kernel measured NOW: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes;
+    FETCH_SIZE is doubled per its gfx950 note; counters are in KB), median over the wrench kernel's dispatches.
+    Returns a dict or None (profiler missing, timeout, nothing parsed) - the committed figure is used then."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    short = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--spinup-seconds", "0.2",
+             "--cpu-seconds", "0", "--no-extras", "--no-roofline-4m", "--no-live-traffic"]
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"hydro_pmc_{counter}_", dir="/tmp")
+        try:
+            res = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + short,
+                                 cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for r in csv.DictReader(f):
+                        if "wrench_tiled_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            vals.append(float(r["Counter_Value"]))
+            if res.returncode != 0 or len(vals) < 8:
+                return None
+            out[counter] = statistics.median(vals) * 1024.0
+        except Exception:                                   # noqa: BLE001 - never lose the headline over the profiler
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"hbm_bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_size_bytes_raw": out["FETCH_SIZE"],
+            "write_size_bytes": out["WRITE_SIZE"],
+            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE on two child runs of "
+                      "bench.py (40 timed steps each), median over the wrench kernel's dispatches; FETCH_SIZE x2 (gfx950)"}
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected
     separately; FETCH_SIZE doubled per the gfx950 correction).  None when not measured."""
@@ -495,6 +537,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-roofline-4m", action="store_true", help="skip the 4 194 304-body second roofline object (N=1 default run)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1: skip the configs[3] strong-scaling leg")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child runs (N=1 default workload); use profiles/traffic.json")
     ap.add_argument("--extras-budget-seconds", type=float, default=150.0,
                     help="secondary measurements are skipped once this much time has gone into them")
     ap.add_argument("--bodies-per-lane", type=int, default=0)
@@ -603,6 +647,15 @@ def main():
         }
         if traffic:
             out["roofline"]["traffic_source"] = traffic.get("source")
+        if traffic and not args.no_live_traffic and args.layout == "tiled":
+            live = measure_traffic_live()
+            if live:
+                out["roofline"]["traffic_committed"] = traffic["hbm_bytes_per_launch"]
+                out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = live["source"]
+                out["roofline"]["traffic_measured"] = "in this run"
+                out["roofline"]["traffic_bytes_per_body_measured"] = live["hbm_bytes_per_launch"] / sc.n
+                out["roofline"]["frac_traffic"] = live["hbm_bytes_per_launch"] / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline_leg(sc, _last_stepped(replicas, args.steps), args.cpu_seconds)

@@ -11,14 +11,14 @@ rm -rf "$out"; mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --cpu-seconds 0 --no-extras --no-roofline-4m > "$out/bench_stats.json" 2> "$out/stats.err" || exit 1
-short="--steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras --no-roofline-4m"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic > "$out/bench_stats.json" 2> "$out/stats.err" || exit 1
+short="--steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 bench.py $short > "$out/bench_fetch.json" 2> "$out/fetch.err" || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 bench.py $short > "$out/bench_write.json" 2> "$out/write.err" || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/sq" -- python3 bench.py $short > "$out/bench_sq.json" 2> "$out/sq.err" || exit 1
 # the second roofline object (bench.py roofline_4m): 4 194 304 bodies, fp16 coefficients, two rotating replicas
-big="--bodies 4194304 --scenes 2 --steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras --no-roofline-4m"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats4m" -- python3 bench.py --bodies 4194304 --scenes 2 --steps 400 --warmup 40 --cpu-seconds 0 --no-extras --no-roofline-4m > "$out/bench_stats4m.json" 2> "$out/stats4m.err" || exit 1
+big="--bodies 4194304 --scenes 2 --steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats4m" -- python3 bench.py --bodies 4194304 --scenes 2 --steps 400 --warmup 40 --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic > "$out/bench_stats4m.json" 2> "$out/stats4m.err" || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch4m" -- python3 bench.py $big > "$out/bench_fetch4m.json" 2> "$out/fetch4m.err" || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write4m" -- python3 bench.py $big > "$out/bench_write4m.json" 2> "$out/write4m.err" || exit 1
 find "$out/stats4m" -name "*kernel_trace.csv" -size +20M -delete
