@@ -485,6 +485,9 @@ def measure_traffic_live(timeout_s: float = 150.0):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
+    # this run is itself being profiled (rocprofv3 -- python bench.py): do not nest profilers
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
     short = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--spinup-seconds", "0.2",
              "--cpu-seconds", "0", "--no-extras", "--no-roofline-4m", "--no-live-traffic"]
     out = {}
