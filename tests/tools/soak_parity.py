@@ -2,7 +2,8 @@
 """Parity soak: many seeded scenes through every fused entry point, EVERY body compared with the fp64 C
 oracle (OpenMP).  Writes gpurun_out/parity_soak.json.   python tests/tools/soak_parity.py [seeds] [n]
 HYDRO_SOAK_SEEDS=226,259 picks explicit seeds; HYDRO_SOAK_FIRST=260 the first seed of a range;
-HYDRO_SOAK_MODES=gated|ungated|both (default both); HYDRO_SOAK_OUT names the JSON."""
+HYDRO_SOAK_MODES=gated|ungated|both (default both); HYDRO_SOAK_LAWS=c2,c3 the buoy / SILVER2-link laws (up to 65 536
+bodies, ragged sizes) instead of c4,c5; HYDRO_SOAK_OUT names the JSON."""
 import json, os, sys, time
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO)
@@ -40,9 +41,14 @@ first = int(os.environ.get("HYDRO_SOAK_FIRST", "100"))
 seed_list = [int(x) for x in os.environ["HYDRO_SOAK_SEEDS"].split(",")] if os.environ.get("HYDRO_SOAK_SEEDS") else range(first, first + seeds)
 modes = {"gated": (True,), "ungated": (False,), "both": (True, False)}[os.environ.get("HYDRO_SOAK_MODES", "both")]
 for seed in seed_list:
-    for law, gated in [(law, g) for law in ("c4", "c5") for g in modes]:
-        fn = scenes.scene_c4 if law == "c4" else scenes.scene_c5
-        sc = fn(n=n, seed=seed, margin=1e-4 if gated else None)
+    for law, gated in [(law, g) for law in os.environ.get("HYDRO_SOAK_LAWS", "c4,c5").split(",") for g in modes]:
+        margin = 1e-4 if gated else None
+        if law == "c2":
+            sc = scenes.scene_c2(n=min(n, 65536) - seed % 61, seed=seed, margin=margin)          # ragged sizes on purpose
+        elif law == "c3":
+            sc = scenes.scene_c3(envs=min(n, 65536) // 19 - seed % 7, seed=seed, margin=margin)
+        else:
+            sc = (scenes.scene_c4 if law == "c4" else scenes.scene_c5)(n=n, seed=seed, margin=margin)
         coeff = "f16" if law == "c5" else "f32"
         rf, rt = c_oracle.wrench(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt, threads=threads)
         ref_bits = None
