@@ -710,3 +710,43 @@ def test_handles_are_independent_across_host_threads(native_built):
     assert not errors, errors
     for k in range(4):
         assert np.array_equal(results[k][:, :3], f_ref) and np.array_equal(results[k][:, 3:], t_ref), k
+
+
+def test_maximum_tiled_size_addresses_every_tile(native_built):
+    """Maximum sizes: the tiled kernels address with 32-bit byte offsets, so a tiled buffer may hold just under 4 GiB.
+    78 copies of a 1 048 576-body scene = 81 788 928 bodies = 1 277 952 state tiles = 4.25 GB (99 % of the limit):
+    every copy must come out with the bits of the 1 048 576-body launch - first, middle and last - and one more copy
+    (4.31 GB) must be refused with HYDRO_E_ARG before anything is launched."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs ~30 GB of device memory")
+    sc = scenes.scene_c5(n=1048576, seed=5)
+    copies, n1 = 78, sc.n
+    t1 = n1 // 64
+    small = HydroEngine(n1, DEV, sc.rho, sc.g)
+    small.set_params(sc.params, "f16")
+    st1 = tiled(sc.state)
+    pv1 = tiled(sc.prev)
+    ref = small.step_wrench_tiled(st1, n1, sc.dt, prev=pv1).clone()
+    small.close()
+    st1[:, 7:13, :] = pv1                                    # previous velocity in the state buffer's own velocity fields ...
+    cur = st1.clone(); cur[:, 7:13, :] = tiled(sc.state)[:, 7:13, :]
+    # ... so the big run can take its previous velocity in place from a second state buffer
+    n = copies * n1
+    big = HydroEngine(n + n1, DEV, sc.rho, sc.g)
+    params = torch.from_numpy(np.ascontiguousarray(sc.params.T)).to(DEV).repeat(1, copies + 1)      # (11, n + n1)
+    big.set_params(params, "f16")
+    del params
+    state = cur.repeat(copies, 1, 1)
+    prev_state = st1.repeat(copies, 1, 1)
+    assert state.numel() * 4 < 1 << 32 and (state.numel() + t1 * 832) * 4 >= 1 << 32
+    out = big.step_wrench_tiled(state, n, sc.dt, prev=prev_state)
+    torch.cuda.synchronize()
+    for k in (0, copies // 2, copies - 1):
+        assert torch.equal(out[k * t1:(k + 1) * t1], ref), k
+    del out
+    # one more copy: 4.31 GB - refused on its size (the same buffers are passed: nothing is dereferenced)
+    with pytest.raises(HydroError, match="4 GiB"):
+        big._check(big._lib.hydro_step_wrench_tiled(big._h, n + n1, state.data_ptr(), 13 * 64, prev_state.data_ptr() + 7 * 64 * 4, 13 * 64,
+                                                   float(sc.dt), ref.data_ptr(), 6 * 64, None))
+    big.close()
