@@ -36,7 +36,10 @@ LOG = open(os.path.join(OUT, "ab.log"), "a")
 def say(*a):
     s = " ".join(str(x) for x in a); print(s, flush=True); LOG.write(s + "\n"); LOG.flush()
 
-for kind, n, coeff, sets in (("c5", 1048576, "f16", 4), ("c5", 1048576, "f32", 4), ("c5", 4194304, "f32", 2)):
+CASES = [("c5", 1048576, "f16", 4), ("c5", 1048576, "f32", 4), ("c5", 4194304, "f32", 2)]
+if os.environ.get("HYDRO_AB_CASES"):            # e.g. "2097152:f16:2,4194304:f16:2"
+    CASES = [("c5", int(a), b, int(c)) for a, b, c in (x.split(":") for x in os.environ["HYDRO_AB_CASES"].split(","))]
+for kind, n, coeff, sets in CASES:
     sc = bench.build_scene(kind, n, 11)
     reps = {}
     for nm in names:
