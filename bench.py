@@ -160,7 +160,7 @@ def spin_up(replicas, stream, seconds: float):
     torch.cuda.synchronize(dev)
 
 
-def timed_steps(replicas, steps: int, warmup: int, stream, world: int, after_step=None):
+def timed_steps(replicas, steps: int, warmup: int, stream, collectives: bool = False, after_step=None):
     """W warm-up steps, then exactly K steps between barrier+synchronize pairs.  Returns
     (wall seconds max over ranks, HIP-event milliseconds on the launch stream).
     after_step(k, replica): called inside the timed region after step k (1-based)."""
@@ -184,7 +184,7 @@ def timed_steps(replicas, steps: int, warmup: int, stream, world: int, after_ste
     hd.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if world > 1 else "cpu")
+    t = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
     hd.all_reduce_max_(t)
     return float(t.item()), float(ev0.elapsed_time(ev1))
 
@@ -264,7 +264,7 @@ def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets
     sc = build_scene(kind, n, seed)
     reps = [Replica(sc, coeff, dev, roll=r * 97, layout=layout) for r in range(sets)]
     spin_up(reps, stream, 0.15)
-    _, ms = timed_steps(reps, steps, 10, stream, 1)
+    _, ms = timed_steps(reps, steps, 10, stream)
     for r in reps:
         r.engine.close()
     us = ms * 1e3 / steps
@@ -377,7 +377,7 @@ def roofline_4m(dev, stream, coeff: str = "f16", n: int = 4194304, sets: int = 2
     return out
 
 
-def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, ke_every: int = 256):
+def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, ke_every: int = 256, collectives: bool = True):
     """BASELINE.json configs[3] as it is stated: 262 144 bodies (seed 4) block-partitioned over the GPUs, every rank
     steps its contiguous shard (no data-path collective); the global kinetic energy is sampled every `ke_every`
     steps by simulate.KineticEnergyMonitor: device reduction, asynchronous all-reduce (RCCL under backend nccl) on
@@ -428,7 +428,7 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, k
     hd.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    tmax = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if world > 1 else "cpu")
+    tmax = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
     hd.all_reduce_max_(tmax)
     wall, ev_ms = float(tmax.item()), float(ev0.elapsed_time(ev1))
     mon.collect(block=True)
@@ -566,7 +566,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    hd.init_process_group()
+    # HYDRO_BENCH_FORCE_GROUP=1 (with HYDRO_DIST_ALWAYS=1): WORLD_SIZE=1 still builds a one-rank process group and takes
+    # the N > 1 code path - how a single-GPU box runs the real RCCL calls (tests/test_rccl_single_rank_gpu.py)
+    force_group = os.environ.get("HYDRO_BENCH_FORCE_GROUP") == "1"
+    hd.init_process_group(force=force_group)
+    multi = world > 1 or force_group
     # one rank per GPU; HYDRO_BENCH_SHARE_GPU=1 (with HYDRO_DIST_BACKEND=gloo) lets several ranks share
     # GPU 0 to rehearse the multi-rank path on a single-GPU box
     ndev = torch.cuda.device_count()
@@ -593,9 +597,9 @@ def main():
     stream = torch.cuda.Stream(dev)
 
     spin_up(replicas, stream, args.spinup_seconds)
-    wall, ev_ms = timed_steps(replicas, args.steps, args.warmup, stream, world)
+    wall, ev_ms = timed_steps(replicas, args.steps, args.warmup, stream, multi)
     # bodies on all ranks (shards differ by at most one body under strong scaling)
-    n_all = torch.tensor([float(sc.n)], dtype=torch.float64, device=hd.collective_device(dev) if world > 1 else "cpu")
+    n_all = torch.tensor([float(sc.n)], dtype=torch.float64, device=hd.collective_device(dev) if multi else "cpu")
     hd.all_reduce_sum_(n_all)
     body_steps = float(n_all.item()) * args.steps
     value = body_steps / wall
@@ -615,8 +619,8 @@ def main():
 
     # N > 1: BASELINE configs[3] as stated (262 144 bodies over the N GPUs, strong scaling) on every rank
     strong = None
-    if world > 1 and not args.no_strong_leg:
-        strong = c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup)
+    if multi and not args.no_strong_leg:
+        strong = c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup, collectives=multi)
 
     if rank == 0:
         traffic = load_traffic(f"{args.workload}:{args.layout}") if world == 1 and not args.bodies else None
@@ -645,6 +649,7 @@ def main():
                          "traffic_measured": "rocprofv3 --pmc passes committed under profiles/ (not re-measured in this run)",
                          **residency(sc.n, coeff, args.scenes)},
             "spinup_seconds": args.spinup_seconds,
+            "collectives": (f"{'nccl (RCCL)' if hd.collective_device(dev).type == 'cuda' else 'gloo'}, {world} rank(s)" if multi else "none (single process)"),
             "global_kinetic_energy_J": [float(x) for x in ke.cpu().tolist()],
             "ke_allreduce_us": ke_us,
         }
@@ -679,7 +684,7 @@ def main():
             try:
                 runs = []
                 for _ in range(5):
-                    _, ms5 = timed_steps(replicas, 200, 20, stream, 1)
+                    _, ms5 = timed_steps(replicas, 200, 20, stream)
                     runs.append(ms5 * 1e3 / 200)
                 runs.sort()
                 out["roofline"]["kernel_us_5x200_runs"] = runs

@@ -32,11 +32,12 @@ def env_rank_world() -> tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend: str | None = None, device_id: int | None = None) -> bool:
-    """Initialise torch.distributed from the env when WORLD_SIZE>1.  Returns True if
-    a group is active.  backend None -> 'nccl' (= RCCL) on GPU, 'gloo' otherwise."""
+def init_process_group(backend: str | None = None, device_id: int | None = None, force: bool = False) -> bool:
+    """Initialise torch.distributed from the env when WORLD_SIZE>1 (or, with force=True, a one-rank group: the way a
+    single-GPU box drives the real RCCL calls).  Returns True if a group is active.  backend None -> 'nccl' (= RCCL)
+    on GPU, 'gloo' otherwise."""
     rank, local_rank, world = env_rank_world()
-    if world <= 1:
+    if world <= 1 and not force:
         return False
     if dist.is_initialized():
         return True
@@ -61,15 +62,23 @@ def collective_device(default: torch.device | str) -> torch.device:
     return torch.device(default)
 
 
+def _collectives_on() -> bool:
+    """A process group with more than one rank - or any group when HYDRO_DIST_ALWAYS=1, which lets a single-GPU box
+    drive the real RCCL calls (a one-rank communicator) through the same code the multi-GPU run takes."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("HYDRO_DIST_ALWAYS") == "1"
+
+
 def all_reduce_sum_(t: torch.Tensor, async_op: bool = False):
     """In-place SUM all-reduce of a small tensor; no-op without a process group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
     return None
 
 
 def all_reduce_max_(t: torch.Tensor):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
@@ -85,5 +94,5 @@ def global_kinetic_energy(local_ke: torch.Tensor, async_op: bool = False):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.barrier()

@@ -1,0 +1,77 @@
+"""The real RCCL code path on a single-GPU box: a ONE-rank communicator (backend "nccl" = RCCL on ROCm) with
+HYDRO_DIST_ALWAYS=1, so that every collective of the N > 1 path - the float64 all-reduce of the kinetic-energy monitor
+issued with async_op=True on its side stream, the max-over-ranks timing, the barriers - goes through RCCL exactly as it
+will on a multi-GPU node (there: same calls, more ranks).  Run in a child process: a process group is per process."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["HYDRO_REPO"])
+from silver2_isaacsim_amd import distributed as hd, scenes
+from silver2_isaacsim_amd.simulate import ClosedLoopSim
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and hd.collective_device(torch.device("cuda", 0)).type == "cuda"
+sc = scenes.scene_c2(n=5000)
+sim = ClosedLoopSim(sc, ke_every=64)
+assert sim.monitor._nccl
+sim.run(256, graph_steps=64)
+sim.synchronize()
+sim.monitor.collect(block=True)
+ref = ClosedLoopSim(sc)
+want = []
+for _ in range(4):
+    ref.run(64, graph_steps=64)
+    st = ref.state().astype(np.float64); m = sc.params[:, 10].astype(np.float64)
+    want.append(float((0.5 * m * (st[:, 7:10] ** 2).sum(1)).sum()))
+t = torch.tensor([2.5], dtype=torch.float64, device="cuda:0")
+hd.all_reduce_max_(t); hd.barrier()
+print(json.dumps({"steps": [s for s, _ in sim.monitor.samples], "ke": [v[0] for _, v in sim.monitor.samples], "want": want,
+                  "host_waits": sim.monitor.waited_on_host, "max": float(t.item())}))
+sim.close(); ref.close()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_monitor_all_reduce_goes_through_rccl(native_built):
+    import json
+    env = dict(os.environ, HYDRO_REPO=REPO, HYDRO_DIST_ALWAYS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["steps"] == [64, 128, 192, 256] and d["max"] == 2.5
+    assert d["ke"] == pytest.approx(d["want"], rel=1e-12)
+
+
+def test_bench_strong_leg_over_rccl(native_built):
+    """bench.py's N > 1 path (weak headline + c4_strong leg + monitor) with the nccl backend and one rank: WORLD_SIZE=1
+    normally means "no process group", HYDRO_BENCH_FORCE_GROUP=1 makes the bench build a one-rank RCCL group and take
+    the multi-rank code path."""
+    import json
+    env = dict(os.environ, HYDRO_DIST_ALWAYS="1", HYDRO_BENCH_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "600", "--warmup", "8", "--bodies", "65536",
+           "--spinup-seconds", "0.1", "--cpu-seconds", "0", "--no-extras"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    cs = d["c4_strong"]
+    assert cs["bodies_this_rank"] == 262144 and cs["kinetic_energy"]["samples"] == 2 and cs["kinetic_energy"]["host_waits"] == 0
+    assert d["collectives"] == "nccl (RCCL), 1 rank(s)"
