@@ -124,6 +124,7 @@ class Replica:
             self.out = torch.empty((6, sc.n), dtype=torch.float32, device=dev)
         self.index = idx
         self._prepared = None
+        self._prepared_ke = None
 
     def step(self):
         if self.layout == "tiled":
@@ -132,6 +133,14 @@ class Replica:
             self._prepared()
         else:
             self.engine.step_wrench(self.state, self.dt, out=self.out, prev=self.prev)
+
+    def step_sampling(self, ke_out):
+        """The same step through the kernel variant that also leaves the kinetic energy of this replica's state in
+        `ke_out` (hydro_step_wrench_tiled_ke: the bodies are in registers anyway, no second pass)."""
+        if self._prepared_ke is None or self._prepared_ke[0] is not ke_out:
+            self._prepared_ke = (ke_out, self.engine.prepare_step_wrench_tiled(self.state, self.n, self.dt, out=self.out, prev=self.prev,
+                                                                                ke_out=ke_out, rotational=True))
+        self._prepared_ke[1]()
 
     def wrench_rows(self, m: int) -> np.ndarray:
         """(m,6) host copy of the first m bodies' wrench."""
@@ -305,41 +314,48 @@ def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int 
             "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9, **residency(sc.n, coeff, 4)}
 
 
+class AosReplica:
+    """One scene replica as the simulator's tensor API hands it over - positions (N,3), orientations (N,4) wxyz,
+    velocities (N,6) - with the previous velocity and the parameters (fp32) inside the engine: one
+    hydro_step_wrench_aos launch per step (168 algorithmic bytes per body-step)."""
+
+    def __init__(self, sc, coeff: str, dev, roll: int, layout: str = "aos"):
+        idx = np.roll(np.arange(sc.n), roll)
+        self.n, self.dt, self.index, self.layout = sc.n, sc.dt, idx, "aos"
+        self.engine = HydroEngine(sc.n, dev, sc.rho, sc.g)
+        self.engine.set_params(sc.params[idx], coeff)
+        self.engine.set_prev_velocity(sc.prev[idx])
+        st = sc.state[idx]
+        self.pos = torch.from_numpy(np.ascontiguousarray(st[:, 0:3])).to(dev)
+        self.quat = torch.from_numpy(np.ascontiguousarray(st[:, [6, 3, 4, 5]])).to(dev)
+        self.vel = torch.from_numpy(np.ascontiguousarray(st[:, 7:13])).to(dev)
+        self.force, self.torque = torch.empty((sc.n, 3), device=dev), torch.empty((sc.n, 3), device=dev)
+        self.state = self.pos                                   # (spin_up / timed_steps only look at .state.device)
+        self._prepared = None
+
+    @property
+    def out(self):
+        return torch.cat([self.force, self.torque], dim=1)
+
+    def step(self):
+        if self._prepared is None:
+            self._prepared = self.engine.prepare_step_wrench_aos(self.pos, self.quat, self.vel, forces=self.force, torques=self.torque)
+        self._prepared(self.dt)
+
+
 def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 13):
     """The simulator-facing entry (hydro_step_wrench_aos: (N,3)/(N,4)/(N,6) tensors in, forces/torques
-    out, previous velocity kept in the engine): 168 algorithmic bytes per body-step."""
+    out, previous velocity kept in the engine): 168 algorithmic bytes per body-step, all of them real traffic."""
     sc = build_scene("c4", n, seed)
-    reps = []
-    for r in range(sets):
-        idx = np.roll(np.arange(sc.n), r * 97)
-        e = HydroEngine(sc.n, dev, sc.rho, sc.g)
-        e.set_params(sc.params[idx]); e.set_prev_velocity(sc.prev[idx])
-        st = sc.state[idx]
-        reps.append((e, torch.from_numpy(np.ascontiguousarray(st[:, 0:3])).to(dev),
-                     torch.from_numpy(np.ascontiguousarray(st[:, [6, 3, 4, 5]])).to(dev),
-                     torch.from_numpy(np.ascontiguousarray(st[:, 7:13])).to(dev),
-                     torch.empty((sc.n, 3), device=dev), torch.empty((sc.n, 3), device=dev)))
-
-    def step(k):
-        e, pos, q, vel, f, t = reps[k % sets]
-        e.step_wrench_aos(pos, q, vel, sc.dt, forces=f, torques=t)
-    with torch.cuda.stream(stream):
-        t0 = time.perf_counter(); k = 0
-        while time.perf_counter() - t0 < 0.15:
-            step(k); k += 1
-            if k % 64 == 0:
-                stream.synchronize()
-        stream.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for k in range(steps):
-            step(k)
-        e1.record(stream); stream.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / steps
+    reps = [AosReplica(sc, "f32", dev, roll=r * 97) for r in range(sets)]
+    spin_up(reps, stream, 0.15)
+    _, ms = timed_steps(reps, steps, 10, stream)
+    us = ms * 1e3 / steps
     for r in reps:
-        r[0].close()
+        r.engine.close()
+    gbs = sc.n * 168 / (us * 1e-6) / 1e9
     return {"n": sc.n, "entry_point": "hydro_step_wrench_aos", "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
-            "algorithmic_gbs": sc.n * 168 / (us * 1e-6) / 1e9, "bytes_per_body_step": 168,
+            "algorithmic_gbs": gbs, "bytes_per_body_step": 168, "frac": gbs / HBM_PEAK_GBS,
             **residency(sc.n, "f32", sets, 12 + 16 + 24 + 24 + 24 + 44)}
 
 
@@ -387,32 +403,46 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, k
     sc = full.shard(rank, world)                             # ... each keeps its contiguous block
     reps = [Replica(sc, "f32", dev, roll=0) for _ in range(2)]      # two buffer sets of the SAME shard (cache-resident sizes)
     mon = KineticEnergyMonitor(reps[0].engine, every=ke_every)
+    ke_dev = torch.zeros(2, dtype=torch.float64, device=dev)         # where the sampling step leaves the shard's pair
     spin_up(reps, stream, 0.3)
     # A shard of 32 768 bodies is one 2.7 us launch: issued one by one the loop is bound by the host call (3.4 us), so
     # GRAPH_STEPS consecutive steps are captured into one HIP graph (the step functions are capture-safe) and the K
-    # timed steps are K // GRAPH_STEPS replays plus K % GRAPH_STEPS eager steps; the monitor samples between replays.
+    # timed steps are K // GRAPH_STEPS replays plus K % GRAPH_STEPS eager steps.  The LAST step of a replay is the
+    # kernel variant that also samples the kinetic energy of the bodies it holds (no extra pass, no extra launch on
+    # the step path but the 2-double second stage); the monitor picks the pair up between replays.
     GRAPH_STEPS = 64
+    assert ke_every % GRAPH_STEPS == 0
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(stream):
+        reps[1].step_sampling(ke_dev)                                 # (prepare outside the capture)
         stream.synchronize()
         with torch.cuda.graph(g, stream=stream):
             for k in range(GRAPH_STEPS):
-                reps[k % 2].step()
+                if k == GRAPH_STEPS - 1:
+                    reps[k % 2].step_sampling(ke_dev)
+                else:
+                    reps[k % 2].step()
         g.replay()
         stream.synchronize()
 
     def run(k_steps, observe):
         done = 0
         for _ in range(k_steps // GRAPH_STEPS):
+            if observe:
+                mon.wait_before_overwrite(stream)
             g.replay()
             done += GRAPH_STEPS
             if observe:
-                mon.observe(done, reps[(done - 1) % 2].state, stream)
+                mon.observe(done, stream=stream, sampled=ke_dev)
         for k in range(k_steps % GRAPH_STEPS):
-            reps[k % 2].step()
             done += 1
-            if observe:
-                mon.observe(done, reps[k % 2].state, stream)
+            sample = observe and done % ke_every == 0
+            if sample:
+                mon.wait_before_overwrite(stream)
+                reps[k % 2].step_sampling(ke_dev)
+                mon.observe(done, stream=stream, sampled=ke_dev)
+            else:
+                reps[k % 2].step()
     with torch.cuda.stream(stream):
         run(warmup, False)
     torch.cuda.synchronize(dev)
@@ -441,19 +471,20 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, k
             "ms_per_step": wall * 1e3 / steps, "kernel_us_rank0": ev_ms * 1e3 / steps,
             "kinetic_energy": {"every_steps": ke_every, "samples": len(mon.samples), "host_waits": mon.waited_on_host,
                                "last_step": last[0] if last else None, "global_J": last[1] if last else None,
-                               "how": "hydro_kinetic_energy_tiled on the step stream, all_reduce(async_op=True) + pinned copy on a side stream"},
+                               "how": "sampled inside the step kernel (hydro_step_wrench_tiled_ke, last step of each graph replay), "
+                                      "all_reduce(async_op=True) + pinned copy on a side stream"},
             "mode": f"hipGraph x{GRAPH_STEPS} steps per replay + eager remainder",
             **residency(sc.n, "f32", 2)}
 
 
-def plugin_rate(batched: bool = True, steps: int = 2000):
+def plugin_rate(batched: bool | str = True, steps: int = 2000, view_buffers: str = "stable"):
     """Host cost of the plugin surface: the 20 prims of the main scene, each with its own HydrodynamicsBehavior on the
     in-memory host of silver2_isaacsim_amd/testing.py; one physics step = 20 callbacks -> (batched) ONE
     hydro_step_wrench_aos launch + one apply.  Wall time per physics step, GPU drained at the end."""
     from silver2_isaacsim_amd import behavior as hb
     from silver2_isaacsim_amd.testing import build_main_scene
     hb.REGISTRY.clear()
-    world, host, prims, behaviors = build_main_scene(batched)
+    world, host, prims, behaviors = build_main_scene(batched, view_buffers=view_buffers)
     for b in behaviors:
         b.on_play()
     for _ in range(100):
@@ -468,52 +499,128 @@ def plugin_rate(batched: bool = True, steps: int = 2000):
         b.on_stop()
     hb.REGISTRY.clear()
     return {"prims": len(prims), "batched": batched, "us_per_physics_step": us, "rtf_at_60hz": 1e6 / us / 60.0,
-            "apply_calls": world.apply_calls, "host": "silver2_isaacsim_amd.testing.FakeHost (in-memory; Isaac Sim cannot run on this box)"}
+            "apply_calls": world.apply_calls,
+            "view_buffers": view_buffers + (" (the same device tensors every step: the BEST case - the launch is prepared once)"
+                                            if view_buffers == "stable" else " (new tensors every step: the launch is re-prepared every step)"),
+            "host": "silver2_isaacsim_amd.testing.FakeHost (in-memory; Isaac Sim cannot run on this box)"}
+
+
+def bound_probes_leg(n: int, dev, stream):
+    """{memory-only, compute-only, kernel} microseconds per launch at n bodies (scripts/probes.py: the product's own
+    arithmetic on inputs that cost no HBM traffic; its traffic shape with a trivial combine; the kernel itself),
+    interleaved in one process, plus the same pair for the array-of-structs entry and the kinetic-energy reduction."""
+    from scripts import probes
+    r = probes.bound_probes(n, dev, stream, rounds=3, reps=120 if n <= 1048576 else 40)
+    us = r["us"]
+    pick = lambda key: next(v for k, v in us.items() if key in k)           # noqa: E731
+    out = {"n": n,
+           "memory_only_us": pick("product pattern"), "compute_only_us": pick("lane-generated"),
+           "compute_l2_resident_inputs_us": pick("L2-resident"), "kernel_us": pick("hydro_step_wrench_tiled"),
+           "aos_memory_only_us": pick("AoS traffic, one row per lane"), "aos_memory_only_chunked_us": pick("AoS traffic, 16-byte"),
+           "aos_kernel_us": pick("hydro_step_wrench_aos"),
+           "ke_memory_only_us": pick("KE reads"), "ke_kernel_us": pick("hydro_kinetic_energy_tiled"),
+           "how": "scripts/probes.py bound_probes: medians of 3 interleaved rounds, rotating buffer sets as the headline"}
+    out["kernel_over_memory_only"] = out["kernel_us"] / out["memory_only_us"]
+    out["compute_only_over_kernel"] = out["compute_only_us"] / out["kernel_us"]
+    out["binding"] = "hbm" if out["memory_only_us"] >= out["compute_only_us"] else "valu"
+    out["aos_kernel_over_memory_only"] = out["aos_kernel_us"] / out["aos_memory_only_us"]
+    out["aos_frac"] = n * 168 / (out["aos_kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    out["ke_frac"] = n * 56 / (out["ke_kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
+def plugin_c3_rate(steps: int = 2000):
+    """BASELINE config 3 through the PLUGIN surface: 19 456 prims (1 024 SILVER2 robots x 19 links), one
+    HydrodynamicsBehavior instance each, scene mode (ONE physics-step subscription for the group, one
+    hydro_step_wrench_aos launch, one apply).  Wall time per physics step on the in-memory host, GPU drained at the end."""
+    from silver2_isaacsim_amd import behavior as hb
+    from silver2_isaacsim_amd.testing import build_c3_scene
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors, sc = build_c3_scene(1024)
+    for b in behaviors:
+        b.on_play()
+    for _ in range(200):
+        host.step(sc.dt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        host.step(sc.dt)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / steps * 1e6
+    subs, fired = len(host._subs), host.callbacks_fired
+    for b in behaviors:
+        b.on_stop()
+    hb.REGISTRY.clear()
+    return {"prims": len(prims), "mode": "scene (one subscription per group)", "us_per_physics_step": us,
+            "rtf_at_120hz": 1e6 / us / 120.0, "body_steps_per_s": len(prims) / (us * 1e-6),
+            "physics_step_subscriptions": subs, "callbacks_per_step": fired / (steps + 200), "apply_calls": world.apply_calls,
+            "host": "silver2_isaacsim_amd.testing.FakeHost, stable-buffer views (in-memory; Isaac Sim cannot run on this box)"}
 
 
 def measure_traffic_live(timeout_s: float = 150.0):
     """HBM bytes per launch of the headline kernel measured NOW: two child runs of this script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes;
     FETCH_SIZE is doubled per its gfx950 note; counters are in KB), median over the wrench kernel's dispatches.
-    Returns a dict or None (profiler missing, timeout, nothing parsed) - the committed figure is used then."""
+    Returns (dict, None) or (None, reason) - the committed figure is used then and the reason goes on the line."""
     import csv
     import glob
     import shutil
+    import signal
     import statistics
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None
+        return None, "rocprofv3 not on PATH"
     # this run is itself being profiled (rocprofv3 -- python bench.py): do not nest profilers
     if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None
+        return None, "this run is itself under a profiler"
     short = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--spinup-seconds", "0.2",
              "--cpu-seconds", "0", "--no-extras", "--no-roofline-4m", "--no-live-traffic"]
     out = {}
-    env = dict(os.environ, TMPDIR="/tmp")
+    # the children are plain single-process runs: nothing of a process group or of the rehearsal knobs may leak into them
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "HYDRO_BENCH_FORCE_GROUP", "HYDRO_DIST_ALWAYS",
+            "HYDRO_BENCH_SHARE_GPU", "HYDRO_DIST_BACKEND")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env["TMPDIR"] = "/tmp"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"hydro_pmc_{counter}_", dir="/tmp")
+        proc = None
         try:
-            res = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + short,
-                                 cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            # own session: on a timeout the WHOLE group goes (rocprofv3 and the bench.py under it, which holds the GPU)
+            proc = subprocess.Popen([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + short,
+                                    cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.communicate()
+                return None, f"{counter} pass timed out after {timeout_s:.0f} s (process group killed)"
             vals = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path, newline="") as f:
                     for r in csv.DictReader(f):
                         if "wrench_tiled_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                             vals.append(float(r["Counter_Value"]))
-            if res.returncode != 0 or len(vals) < 8:
-                return None
+            if proc.returncode != 0:
+                return None, f"{counter} pass exited with {proc.returncode}: {(err or '').strip()[-300:]}"
+            if len(vals) < 8:
+                return None, f"{counter} pass: only {len(vals)} dispatches of the wrench kernel in the counter file"
             out[counter] = statistics.median(vals) * 1024.0
-        except Exception:                                   # noqa: BLE001 - never lose the headline over the profiler
-            return None
+        except Exception as e:                              # noqa: BLE001 - never lose the headline over the profiler
+            if proc is not None and proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                    proc.communicate()
+                except Exception:                           # noqa: BLE001
+                    pass
+            return None, f"{counter} pass: {e!r}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return {"hbm_bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_size_bytes_raw": out["FETCH_SIZE"],
             "write_size_bytes": out["WRITE_SIZE"],
             "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE on two child runs of "
-                      "bench.py (40 timed steps each), median over the wrench kernel's dispatches; FETCH_SIZE x2 (gfx950)"}
+                      "bench.py (40 timed steps each), median over the wrench kernel's dispatches; FETCH_SIZE x2 (gfx950)"}, None
 
 
 def load_traffic(workload: str):
@@ -526,6 +633,42 @@ def load_traffic(workload: str):
         return rec
     except Exception:
         return None
+
+
+def self_launch(n: int) -> int:
+    """Run this script as `n` ranks of one node (one process per GPU, RCCL between them) and relay rank 0's JSON line.
+    Returns the exit code for the parent.  Nothing here initialises the GPU: `torch.cuda.device_count()` only counts."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("HYDRO_BENCH_SHARE_GPU") == "1"       # rehearsal: several ranks on GPU 0 (with HYDRO_DIST_BACKEND=gloo)
+    if ndev < n and not (share and ndev >= 1):
+        sys.stderr.write(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible; refusing to benchmark fewer GPUs than asked "
+                         f"(set HYDRO_BENCH_SHARE_GPU=1 HYDRO_DIST_BACKEND=gloo to rehearse the multi-rank path on one GPU)\n")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    sys.stderr.write(f"bench.py: --gpus {n} without a torchrun environment: launching {' '.join(cmd[1:8])} ...\n")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for cand in res.stdout.splitlines():
+        cand = cand.strip()
+        if cand.startswith("{") and '"metric"' in cand:
+            line = cand
+    if res.returncode != 0 or line is None:
+        sys.stderr.write(res.stdout)
+        sys.stderr.write(f"bench.py: the {n}-rank run failed (exit code {res.returncode}, JSON line {'found' if line else 'missing'})\n")
+        return res.returncode or 3
+    if json.loads(line).get("n_gpus") != n:
+        sys.stderr.write(f"bench.py: the child reported n_gpus={json.loads(line).get('n_gpus')}, expected {n}\n")
+        return 4
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 def main():
@@ -542,7 +685,7 @@ def main():
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1: skip the configs[3] strong-scaling leg")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (N=1 default workload); use profiles/traffic.json")
-    ap.add_argument("--extras-budget-seconds", type=float, default=150.0,
+    ap.add_argument("--extras-budget-seconds", type=float, default=200.0,
                     help="secondary measurements are skipped once this much time has gone into them")
     ap.add_argument("--bodies-per-lane", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -554,6 +697,12 @@ def main():
                     help="tiled = engine-native tiled SoA (hydro_step_wrench_tiled); soa = plain field pointers")
     args = ap.parse_args()
 
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("HYDRO_BENCH_FORCE_GROUP") != "1":
+        # `python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (a child
+        # `python -m torch.distributed.run`), BEFORE anything in this process touches the GPU, and relay rank 0's JSON
+        # line and the exit code.  Never fall through to a one-GPU run that would report n_gpus = 1.
+        raise SystemExit(self_launch(args.gpus))
+
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner
     # on stdout when the first communicator is created), so file descriptor 1 is pointed at stderr for the whole
     # run and the line goes to a saved copy of the real stdout at the end.
@@ -562,8 +711,9 @@ def main():
     os.dup2(2, 1)
 
     rank, local_rank, world = hd.env_rank_world()
-    if world != max(1, args.gpus) and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != max(1, args.gpus) and not (world == 1 and os.environ.get("HYDRO_BENCH_FORCE_GROUP") == "1"):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or plain `python bench.py --gpus N`, "
+                         f"which starts them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # HYDRO_BENCH_FORCE_GROUP=1 (with HYDRO_DIST_ALWAYS=1): WORLD_SIZE=1 still builds a one-rank process group and takes
@@ -603,9 +753,14 @@ def main():
     hd.all_reduce_sum_(n_all)
     body_steps = float(n_all.item()) * args.steps
     value = body_steps / wall
-    kernel_us = ev_ms * 1e3 / args.steps
+    kernel_us = ev_ms * 1e3 / args.steps              # HIP events on the launch stream around the K timed steps
+    step_us = wall * 1e6 / args.steps                 # the interval `value` and `ms_per_step` are computed from
     bpb = BYTES_PER_BODY[coeff]
-    achieved = sc.n * bpb / (kernel_us * 1e-6) / 1e9
+    # ONE clock for `value` and `roofline.frac`: algorithmic bytes per launch / (timed interval / K).  The event figure
+    # of the same K steps (always a little shorter: it leaves out the host's synchronisation at both ends) is kept as
+    # `frac_contract_steps`, the median of 5 x 200 steps as `frac_median_of_5`.
+    achieved = sc.n * bpb / (step_us * 1e-6) / 1e9
+    achieved_events = sc.n * bpb / (kernel_us * 1e-6) / 1e9
 
     # the one collective of the path: global kinetic energy (every rank reduces its shard on device)
     with torch.cuda.stream(stream):
@@ -639,13 +794,16 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
                          "kernel": "wrench_tiled_kernel" if args.layout == "tiled" else "wrench_soa_kernel",
-                         "kernel_us": kernel_us,
+                         "clock": "the timed interval of `value` (wall time between the barrier + synchronize pairs, max over "
+                                  "ranks) / steps; `kernel_us` / `frac_contract_steps` = HIP events around the same steps",
+                         "step_us": step_us, "kernel_us": kernel_us,
+                         "achieved_contract_steps": achieved_events, "frac_contract_steps": achieved_events / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": sc.n * bpb,
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          # what the counters say: the kernel moves 122 B per body (fp16 coefficients), not the 130
                          # algorithmic ones - frac_traffic is the honest bandwidth fraction
                          "traffic_bytes_per_body": TRAFFIC_BYTES_PER_BODY[coeff],
-                         "frac_traffic": sc.n * TRAFFIC_BYTES_PER_BODY[coeff] / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "frac_traffic": sc.n * TRAFFIC_BYTES_PER_BODY[coeff] / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "traffic_measured": "rocprofv3 --pmc passes committed under profiles/ (not re-measured in this run)",
                          **residency(sc.n, coeff, args.scenes)},
             "spinup_seconds": args.spinup_seconds,
@@ -656,14 +814,16 @@ def main():
         if traffic:
             out["roofline"]["traffic_source"] = traffic.get("source")
         if traffic and not args.no_live_traffic and args.layout == "tiled":
-            live = measure_traffic_live()
-            if live:
+            live, why_not = measure_traffic_live()
+            if live is None:
+                out["roofline"]["traffic_live_skipped"] = why_not
+            else:
                 out["roofline"]["traffic_committed"] = traffic["hbm_bytes_per_launch"]
                 out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = live["source"]
                 out["roofline"]["traffic_measured"] = "in this run"
                 out["roofline"]["traffic_bytes_per_body_measured"] = live["hbm_bytes_per_launch"] / sc.n
-                out["roofline"]["frac_traffic"] = live["hbm_bytes_per_launch"] / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                out["roofline"]["frac_traffic"] = live["hbm_bytes_per_launch"] / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline_leg(sc, _last_stepped(replicas, args.steps), args.cpu_seconds)
@@ -708,6 +868,9 @@ def main():
                     ex[key] = fn(*fa, **fk)
                 except Exception as e:                      # noqa: BLE001 - extras never break the headline
                     ex[key] = {"error": repr(e)}
+            # which bound binds: memory-only / compute-only probes beside the kernels themselves (verdict r2 item 2)
+            guarded("bound_probes_1m", bound_probes_leg, 1048576, dev, stream)
+            guarded("bound_probes_4m", bound_probes_leg, 4194304, dev, stream)
             guarded("c2_4096", quick_rate, "c2", 4096, "f32", dev, stream, steps=200)
             guarded("c3_19456", quick_rate, "c3", 19456, "f32", dev, stream, steps=200)
             guarded("c4_shard_32768", quick_rate, "c4", 32768, "f32", dev, stream, steps=200)
@@ -722,7 +885,10 @@ def main():
             guarded("plain_soa_f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
             guarded("aos_entry_1048576", aos_rate, 1048576, dev, stream)
             guarded("plugin_20prims_us_per_step", plugin_rate, True)
+            guarded("plugin_20prims_fresh_tensors_every_step", plugin_rate, True, steps=1000, view_buffers="fresh")
+            guarded("plugin_20prims_callbacks_mode", plugin_rate, "callbacks", steps=1000)
             guarded("plugin_20prims_per_prim_mode", plugin_rate, False, steps=500)
+            guarded("plugin_c3_19456prims", plugin_c3_rate)
             guarded("closed_loop_c2_4096", closed_loop_rate, "c2", 4096)
             guarded("closed_loop_c2_4096_unfused", closed_loop_rate, "c2", 4096, fused=False)
             guarded("closed_loop_c3_1024envs_implicit", closed_loop_rate, "c3", 19456, implicit_drag=True)

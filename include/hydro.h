@@ -37,8 +37,10 @@ extern "C" {
 #endif
 
 /* 0.2.0: scene scalars are doubles (hydro_set_scene), hydro_set_semantics, waves_per_simd in hydro_set_tuning
- * 0.3.0: dt is a double in every step / integrate entry point; the model is evaluated in fp64 */
-#define HYDRO_VERSION 0x000300
+ * 0.3.0: dt is a double in every step / integrate entry point; the model is evaluated in fp64
+ * 0.4.0: hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke (kinetic energy sampled inside the step kernel),
+ *        hydro_reserve_soa; the engine holds 68 B per body and makes its plain-SoA copies on first use */
+#define HYDRO_VERSION 0x000400
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
@@ -63,8 +65,14 @@ int         hydro_device_count(int *count);
 
 /* Lifetime.  One engine = one device + up to `capacity` bodies.  Replaces the construction of
  * one WarpHydrodynamicsWrapper per prim (warp_hydrodynamics_wrapper.py:10-77; one instance per
- * body, hydrodynamics_behavior.py:155-169) with one batched object. */
+ * body, hydrodynamics_behavior.py:155-169) with one batched object.
+ * Device memory: 68 B per body of capacity - the tiled parameter record (44 B) and the tiled previous velocity
+ * (24 B) - plus 1/16 B of reduction scratch.  The entry points that take PLAIN field pointers (hydro_step_wrench,
+ * hydro_step_wrench_ext, hydro_step_components) work on plain-SoA copies of the parameters / previous velocity
+ * (82 B per body more) that are made on their FIRST call - which therefore allocates and synchronises once and
+ * cannot be captured into a HIP graph; call it once before capturing, or hydro_reserve_soa() up front. */
 int         hydro_create(int device, int64_t capacity, hydro_t **out);
+int         hydro_reserve_soa(hydro_t *h);
 int         hydro_destroy(hydro_t *h);
 const char *hydro_last_error(const hydro_t *h);
 int64_t     hydro_capacity(const hydro_t *h);
@@ -140,6 +148,17 @@ int hydro_step_wrench_tiled(hydro_t *h, int64_t n, const float *state, int64_t s
                             const float *prev, int64_t prev_tile_stride, double dt,
                             float *wrench, int64_t wrench_tile_stride, void *stream);
 
+/* The same step, sampling the kinetic energy on the way ("reduced in-kernel"): the kernel adds
+ * 1/2 m |v|^2 (and, with `rotational`, the box-inertia term) of the bodies it already holds in registers - the state
+ * it READS, i.e. the state the previous step left - reduces over the wavefront and the block, and a fixed-order
+ * second stage leaves [translational, rotational] in ke_out_dev[0..1] (device memory, fp64).  No second pass over
+ * the state, the wrench bits are those of hydro_step_wrench_tiled, the energy bits those of
+ * hydro_kinetic_energy_tiled on the same state.  For the monitor that all-reduces the pair over RCCL every K steps. */
+int hydro_step_wrench_tiled_ke(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
+                               const float *prev, int64_t prev_tile_stride, double dt,
+                               float *wrench, int64_t wrench_tile_stride,
+                               int rotational, double *ke_out_dev, void *stream);
+
 /* Edges of the tiled layout: simulator tensors -> tiled state and tiled
  * wrench -> forces / torques (both staged through LDS), and a generic plain-SoA <-> tiled
  * repack of `fields` field pointers. */
@@ -155,8 +174,9 @@ int hydro_repack(hydro_t *h, int64_t n, int fields, float *const soa[], float *t
  * back (apply_forces_and_torques_at_pos, :229-234): positions (n,3), orientations (n,4) in the
  * simulator's WXYZ order when quat_xyzw == 0 (the reorder of :194 is done in the load) or in the
  * calculators' XYZW order when quat_xyzw != 0, velocities (n,6) [lin|ang]; forces (n,3),
- * torques (n,3).  All five tensors 16-byte aligned.  Transposition is staged through LDS.
- * Previous velocity lives in the engine, as for hydro_step_wrench. */
+ * torques (n,3).  All five tensors 16-byte aligned.  Every lane moves its body's rows with 12- / 16- / 24-byte
+ * accesses (a wave-instruction covers a contiguous run of whole lines; staging the transposition through LDS was
+ * measured and is slower).  Previous velocity lives in the engine, as for hydro_step_wrench. */
 int hydro_step_wrench_aos(hydro_t *h, int64_t n, const float *positions, const float *orientations, int quat_xyzw,
                           const float *velocities, double dt, float *forces, float *torques, void *stream);
 
@@ -179,9 +199,12 @@ int hydro_step_components_aos(hydro_t *h, int64_t n, const float *position, cons
                               const float *angular_accel, float *const out[8], float *ratio, void *stream);
 
 /* Kinetic energy of the n bodies: out_dev[0] = sum 1/2 m |v|^2, out_dev[1] = sum 1/2 w^T I w (box
- * inertia; 0 unless `rotational`).  Two-stage deterministic fp64 reduction on device; the
+ * inertia; 0 unless `rotational`), every body in fp64.  Two-stage deterministic reduction on device (wave64
+ * shuffles -> LDS -> one fp64 pair per block of 256 bodies -> fixed-order second stage, no atomics); the
  * result stays on the device so that the caller can all-reduce it over RCCL.  New
- * functionality named by BASELINE.json north_star; absent from the reference. */
+ * functionality named by BASELINE.json north_star; absent from the reference.
+ * These are the stand-alone entries (one pass over the state: 56 B per body with the rotational term);
+ * hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke sample the same pair, same bits, inside a step. */
 int hydro_kinetic_energy(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], int rotational,
                          double *out_dev, void *stream);
 int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride, int rotational,
@@ -209,6 +232,14 @@ int hydro_step_fused_tiled(hydro_t *h, int64_t n, const float *state, int64_t st
                            const float *prev, int64_t prev_tile_stride, double dt,
                            float *state_out, int64_t out_tile_stride,
                            float *wrench, int64_t wrench_tile_stride, int implicit_drag, void *stream);
+
+/* The same, sampling the kinetic energy of the state it WRITES (the state after this step) into
+ * ke_out_dev[0..1]; see hydro_step_wrench_tiled_ke.  State bits are those of hydro_step_fused_tiled. */
+int hydro_step_fused_tiled_ke(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
+                              const float *prev, int64_t prev_tile_stride, double dt,
+                              float *state_out, int64_t out_tile_stride,
+                              float *wrench, int64_t wrench_tile_stride, int implicit_drag,
+                              int rotational, double *ke_out_dev, void *stream);
 
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
  * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1), resident waves per

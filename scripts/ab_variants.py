@@ -52,7 +52,9 @@ for kind, n, coeff, sets in CASES:
         nat.SIGNATURES.update(full)
         if not hasattr(nat._lib, "hydro_set_semantics"):
             HydroEngine.set_semantics = lambda self, *_a, **_k: None
-        reps[nm] = [bench.Replica(sc, coeff, dev, roll=7919 * k, layout=os.environ.get("HYDRO_AB_LAYOUT", "tiled")) for k in range(sets)]
+        layout = os.environ.get("HYDRO_AB_LAYOUT", "tiled")          # tiled | soa | aos (the simulator-facing entry)
+        cls = bench.AosReplica if layout == "aos" else bench.Replica
+        reps[nm] = [cls(sc, coeff, dev, roll=7919 * k, layout=layout) for k in range(sets)]
         if opt:
             import re
             w = re.search(r"w(\d)", opt); b = re.search(r"b(\d+)", opt)

@@ -31,7 +31,7 @@ with torch.cuda.stream(stream):
     print(f"engine.step_wrench_tiled      host issue {a[0]:6.2f} us/call   wall {a[1]:6.2f} us/step")
     lib = eng._lib
     args = (eng._h, ctypes.c_int64(sc.n), ctypes.c_void_p(S.data_ptr()), ctypes.c_int64(13 * 64), ctypes.c_void_p(P.data_ptr()),
-            ctypes.c_int64(6 * 64), ctypes.c_float(sc.dt), ctypes.c_void_p(O.data_ptr()), ctypes.c_int64(6 * 64),
+            ctypes.c_int64(6 * 64), ctypes.c_double(sc.dt), ctypes.c_void_p(O.data_ptr()), ctypes.c_int64(6 * 64),
             ctypes.c_void_p(stream.cuda_stream))
     fn = lib.hydro_step_wrench_tiled
     b = bench(lambda: fn(*args))

@@ -1,0 +1,220 @@
+// Measurement probes (not part of the product; bench.py's `bound_probes` extras and scripts/probes.py use them):
+//   * memory-only: what the MI355X delivers for the traffic shape of the tiled wrench kernel - 98 B read + 24 B
+//     written per body (fp16-coefficient records) - with different access widths, the read-only / copy ceilings
+//     beside it, and the traffic shapes of the array-of-structs entry and of the kinetic-energy reduction;
+//   * compute-only: the REAL per-body arithmetic (hydro_body.h solve_wrench, the product's code) on inputs that cost
+//     no HBM traffic - generated per lane, or read from 64 tiles that stay in L2 - with one 4-byte store per lane.
+// Together with the product kernel's own time they say which bound binds.
+//   records per tile of 64 bodies: state [13][64] f32 (p_x, p_y skipped: 2 816 B used), prev [6][64] f32 (1 536 B),
+//   params 1 920 B (4 x f32 + 7 x f16 per body), wrench [6][64] f32 (1 536 B)
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../silver2_isaacsim_amd/csrc/hydro_body.h"
+
+struct PArgs { const float* st; const float* pv; const float* prm; float* out; uint32_t tiles; };
+using f4 = float __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ T ldnt(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T> __device__ __forceinline__ void stnt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
+// P0: the product's pattern - 21 four-byte loads + 7 two-byte loads, 6 four-byte stores per lane
+__global__ void __launch_bounds__(256) probe_dword(const PArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (tile >= a.tiles) return;
+    const float* s = a.st + (size_t)tile * 832 + lane; const float* p = a.pv + (size_t)tile * 384 + lane;
+    const float* q = a.prm + (size_t)tile * 480 + lane;
+    const unsigned short* hq = reinterpret_cast<const unsigned short*>(a.prm + (size_t)tile * 480 + 256) + lane;
+    float acc = 0.0f;
+#pragma unroll
+    for (int f = 2; f < 13; ++f) acc += ldnt(s + f * 64);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) acc += ldnt(p + f * 64);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc += ldnt(q + f * 64);
+#pragma unroll
+    for (int f = 0; f < 7; ++f) acc += (float)ldnt(hq + f * 64);
+    float* o = a.out + (size_t)tile * 384 + lane;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) stnt(o + f * 64, acc + (float)f);
+}
+
+// P1: the same bytes as sixteen-byte accesses (what an LDS-transposed kernel would issue): 2.75 + 1.5 + 1.875 loads
+// and 1.5 stores per lane.  STORE = false: the read-only ceiling of this shape.
+template <bool STORE>
+__global__ void __launch_bounds__(256) probe_x4(const PArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (tile >= a.tiles) return;
+    const f4* s = reinterpret_cast<const f4*>(a.st + (size_t)tile * 832 + 128);      // skip p_x, p_y (2 x 256 B)
+    const f4* p = reinterpret_cast<const f4*>(a.pv + (size_t)tile * 384);
+    const f4* q = reinterpret_cast<const f4*>(a.prm + (size_t)tile * 480);
+    f4 acc = ldnt(s + lane) + ldnt(s + 64 + lane) + ldnt(p + lane) + ldnt(q + lane);
+    if (lane < 48u) acc += ldnt(s + 128 + lane);
+    if (lane < 32u) acc += ldnt(p + 64 + lane);
+    if (lane < 56u) acc += ldnt(q + 64 + lane);
+    f4* o = reinterpret_cast<f4*>(a.out + (size_t)tile * 384);
+    if constexpr (STORE) {
+        stnt(o + lane, acc);
+        if (lane < 32u) stnt(o + 64 + lane, acc);
+    } else if (acc.x == 1.2345e-33f) {
+        o[lane] = acc;                                                              // never true: keeps the loads alive
+    }
+}
+
+// P3: plain float4 copy 1:1 of the same total bytes (the guide's "copy ceiling" shape)
+__global__ void __launch_bounds__(256) probe_copy(const f4* __restrict__ src, f4* __restrict__ dst, uint32_t n4)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) stnt(dst + i, ldnt(src + i));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute-only probes: the product's arithmetic, no HBM reads, 4 B written per body
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float h2f(unsigned short b) { return __half2float(__ushort_as_half(b)); }
+
+// MODE 0: every input generated per lane from four hashed values (C5-like ranges: boxes 0.1-1.6 m, half of them
+//         straddling the surface, |v| and |w| up to ~1.7, coefficients around the README defaults, stored as fp16 bits
+//         so that the seven conversions of the product kernel are there too);
+// MODE 1: the product's 28 loads, from records of 64 tiles that are re-read by every wave and therefore stay in L2
+//         (the buffers' first 64 tiles must hold a real scene: scripts/probes.py fills them).
+template <int MODE>
+__global__ void __launch_bounds__(256) probe_compute(const PArgs a, double rho, double g, double inv_dt)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (tile >= a.tiles) return;
+    hydro::BodyIn b;
+    float pv[6], mass;
+    if constexpr (MODE == 0) {
+        uint32_t h = i * 2654435761u + 12345u;
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h = h * 1664525u + 1013904223u; u[k] = (float)(h >> 8) * (1.0f / 16777216.0f); }
+        b.px = 0.0f; b.py = 0.0f;
+        b.dimx = 0.1f + 1.5f * u[0]; b.dimy = 0.1f + 1.5f * u[1]; b.dimz = 0.1f + 1.5f * u[2];
+        b.pz = (u[3] - 0.6f) * 1.5f;
+        const float qa = u[0] - 0.5f, qb = u[1] - 0.5f, qc = u[2] - 0.5f, qd = u[3] + 0.5f;
+        const float qn = __builtin_amdgcn_rsqf(qa * qa + qb * qb + qc * qc + qd * qd);
+        b.qx = qa * qn; b.qy = qb * qn; b.qz = qc * qn; b.qw = qd * qn;
+        b.vx = 2.0f * u[1] - 1.0f; b.vy = 2.0f * u[2] - 1.0f; b.vz = 2.0f * u[3] - 1.0f;
+        b.wx = 1.0f - 2.0f * u[2]; b.wy = 2.0f * u[0] - 1.0f; b.wz = 1.0f - 2.0f * u[1];
+        pv[0] = b.vx - 0.01f * u[0]; pv[1] = b.vy + 0.01f * u[1]; pv[2] = b.vz - 0.01f * u[2];
+        pv[3] = b.wx + 0.01f * u[3]; pv[4] = b.wy - 0.01f * u[1]; pv[5] = b.wz + 0.01f * u[0];
+        const uint32_t hb = 0x3c00u + (h >> 24);                       // fp16 bits of 1.0 .. 1.25
+        b.cd_lin = h2f((unsigned short)hb); b.cd_ang = h2f((unsigned short)(hb - 0x100u));
+        b.damp_lin = 300.0f * h2f((unsigned short)(hb + 3u)); b.damp_ang = 150.0f * h2f((unsigned short)(hb + 5u));
+        b.lift = h2f((unsigned short)(hb - 0x200u)); b.am_lin = 0.05f * h2f((unsigned short)(hb + 7u));
+        b.am_ang = 0.02f * h2f((unsigned short)(hb + 9u));
+        mass = 400.0f * b.dimx * b.dimy * b.dimz + 0.5f;
+    } else {
+        const uint32_t lt = tile & 63u;
+        const float* s = a.st + (size_t)lt * 832 + lane; const float* p = a.pv + (size_t)lt * 384 + lane;
+        const float* q = a.prm + (size_t)lt * 480 + lane;
+        const unsigned short* hq = reinterpret_cast<const unsigned short*>(a.prm + (size_t)lt * 480 + 256) + lane;
+        b.px = 0.0f; b.py = 0.0f; b.pz = s[2 * 64];
+        b.qx = s[3 * 64]; b.qy = s[4 * 64]; b.qz = s[5 * 64]; b.qw = s[6 * 64];
+        b.vx = s[7 * 64]; b.vy = s[8 * 64]; b.vz = s[9 * 64]; b.wx = s[10 * 64]; b.wy = s[11 * 64]; b.wz = s[12 * 64];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) pv[f] = p[f * 64];
+        b.dimx = q[0]; b.dimy = q[64]; b.dimz = q[128]; mass = q[192];
+        b.cd_lin = h2f(hq[0]); b.cd_ang = h2f(hq[64]); b.damp_lin = h2f(hq[128]); b.damp_ang = h2f(hq[192]);
+        b.lift = h2f(hq[256]); b.am_lin = h2f(hq[320]); b.am_ang = h2f(hq[384]);
+    }
+    const hydro::Wrench w = hydro::solve_wrench(b, pv, mass, rho, g, inv_dt, false);
+    stnt(a.out + (size_t)tile * 64 + lane, ((w.fx + w.fy) + (w.fz + w.tx)) + (w.ty + w.tz));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// memory-only probe of the array-of-structs entry (hydro_step_wrench_aos, fp32 parameters): 168 B per body =
+// positions 12 + orientations 16 + velocities 24 + previous velocity 24 read and 24 written + parameters 44 in,
+// forces 12 + torques 12 out.  WIDE: the simulator tensors as whole 16-byte chunks per wave (what the LDS-staged
+// kernel issues: 48 + 64 + 32 + 64 lanes); otherwise one 12- / 16- / 24-byte row per lane (dwordx3 / x4 / x4+x2).
+// ---------------------------------------------------------------------------------------------------------------
+struct AArgs { const float* pos; const float* quat; const float* vel; float* force; float* torque; float* pv; const float* prm; uint32_t n; };
+using f2 = float __attribute__((ext_vector_type(2)));
+using f3 = float __attribute__((ext_vector_type(3)));
+template <bool WIDE>
+__global__ void __launch_bounds__(256) probe_aos(const AArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (i >= a.n) return;                              // n is a multiple of 64 here
+    const uint32_t w0 = tile * 64u;
+    float acc = 0.0f;
+    if constexpr (WIDE) {
+        const f4* p4 = reinterpret_cast<const f4*>(a.pos + (size_t)w0 * 3);
+        const f4* v4 = reinterpret_cast<const f4*>(a.vel + (size_t)w0 * 6);
+        f4 t = ldnt(v4 + lane);
+        if (lane < 48u) t += ldnt(p4 + lane);
+        if (lane < 32u) t += ldnt(v4 + 64 + lane);
+        acc = (t.x + t.y) + (t.z + t.w);
+    } else {
+        const f3 p = *reinterpret_cast<const f3*>(a.pos + (size_t)i * 3);
+        const f4 v0 = *reinterpret_cast<const f4*>(a.vel + (size_t)i * 6);
+        const f2 v1 = *reinterpret_cast<const f2*>(a.vel + (size_t)i * 6 + 4);
+        acc = (p.x + p.y + p.z) + (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y);
+    }
+    const f4 q = ldnt(reinterpret_cast<const f4*>(a.quat) + i);
+    acc += (q.x + q.y) + (q.z + q.w);
+    float* pv = a.pv + (size_t)tile * 384 + lane;
+    const float* prm = a.prm + (size_t)tile * 704 + lane;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) acc += ldnt(pv + f * 64);
+#pragma unroll
+    for (int f = 0; f < 11; ++f) acc += ldnt(prm + f * 64);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) stnt(pv + f * 64, acc + (float)f);
+    if constexpr (WIDE) {
+        f4 o; o.x = acc; o.y = acc + 1.0f; o.z = acc + 2.0f; o.w = acc + 3.0f;
+        if (lane < 48u) {
+            stnt(reinterpret_cast<f4*>(a.force + (size_t)w0 * 3) + lane, o);
+            stnt(reinterpret_cast<f4*>(a.torque + (size_t)w0 * 3) + lane, o);
+        }
+    } else {
+        f3 o; o.x = acc; o.y = acc + 1.0f; o.z = acc + 2.0f;
+        *reinterpret_cast<f3*>(a.force + (size_t)i * 3) = o;
+        *reinterpret_cast<f3*>(a.torque + (size_t)i * 3) = o;
+    }
+}
+
+// memory-only probe of the kinetic-energy reduction on tiled records: orientation, linear and angular velocity
+// (10 of the 13 state fields) + dimensions and mass from the fp32 parameter record = 56 B per body, nothing written
+__global__ void __launch_bounds__(256) probe_ke(const PArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (tile >= a.tiles) return;
+    const float* s = a.st + (size_t)tile * 832 + lane; const float* q = a.prm + (size_t)tile * 704 + lane;
+    float acc = 0.0f;
+#pragma unroll
+    for (int f = 3; f < 13; ++f) acc += ldnt(s + f * 64);
+    acc += ldnt(q) + ldnt(q + 64) + ldnt(q + 128) + ldnt(q + 640);
+    if (acc == 1.2345e-33f) a.out[i] = acc;                                           // never true: keeps the loads alive
+}
+
+extern "C" int probe_launch_aos(int wide, const AArgs* a, void* stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((a->n + 255) / 256), blk(256);
+    if (wide) hipLaunchKernelGGL(probe_aos<true>, grid, blk, 0, s, *a);
+    else hipLaunchKernelGGL(probe_aos<false>, grid, blk, 0, s, *a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int probe_launch(int which, const PArgs* a, const void* src, void* dst, uint32_t n4, void* stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((a->tiles * 64 + 255) / 256), blk(256);
+    switch (which) {
+        case 0: hipLaunchKernelGGL(probe_dword, grid, blk, 0, s, *a); break;
+        case 1: hipLaunchKernelGGL(probe_x4<true>, grid, blk, 0, s, *a); break;
+        case 2: hipLaunchKernelGGL(probe_x4<false>, grid, blk, 0, s, *a); break;
+        case 3: hipLaunchKernelGGL(probe_copy, dim3((n4 + 255) / 256), blk, 0, s, static_cast<const f4*>(src), static_cast<f4*>(dst), n4); break;
+        case 4: hipLaunchKernelGGL(probe_compute<0>, grid, blk, 0, s, *a, 1025.0, 9.81, 60.0); break;
+        case 5: hipLaunchKernelGGL(probe_compute<1>, grid, blk, 0, s, *a, 1025.0, 9.81, 60.0); break;
+        case 6: hipLaunchKernelGGL(probe_ke, grid, blk, 0, s, *a); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -43,8 +43,13 @@ SIGNATURES = {
     "hydro_step_wrench_ext": (c_int, [c_void_p, c_int64, _FP, _FP, c_double, _FP, c_void_p]),
     "hydro_step_wrench_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                         c_void_p, c_int64, c_void_p]),
+    "hydro_step_wrench_tiled_ke": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
+                                           c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hydro_step_fused_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                        c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "hydro_step_fused_tiled_ke": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
+                                          c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "hydro_reserve_soa": (c_int, [c_void_p]),
     "hydro_integrate_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                       c_void_p, c_int64, c_void_p]),
     "hydro_pack_state_aos": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),

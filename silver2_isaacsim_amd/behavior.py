@@ -10,13 +10,16 @@ JSON override rule, same error behaviour (state-fetch failures skip the step,
 What changes is underneath.  The reference creates one calculator and one
 `RigidPrimView` of size 1 per prim and pays ~40 GPU launches per prim per step
 (SURVEY.md 3.2).  Here every instance registers its prim with a process-wide
-`EngineRegistry`; the first physics-step callback of a step fetches the poses
-and velocities of ALL registered prims through one batched view, runs ONE fused
-kernel (`hydro_step_wrench_aos`: quaternion reorder, finite-difference
-acceleration, nine-component model, lever arms, sum, clamp) and applies all
-wrenches with one call; the other callbacks of that step return immediately.
-`batched=False` keeps the reference's one-view-per-prim flow (still one fused
-launch per prim instead of ~40).
+`EngineRegistry`, and the GROUP - not the prim - subscribes to the physics-step
+event: one callback per step fetches the poses and velocities of ALL registered
+prims through one batched view, runs ONE fused kernel (`hydro_step_wrench_aos`:
+quaternion reorder, finite-difference acceleration, nine-component model, lever
+arms, sum, clamp) and applies all wrenches with one call.  Host time per physics
+step is O(1) in the number of prims (19 456 prims of config 3: one callback, not
+19 456).  `batched="callbacks"` keeps one subscription per prim as the reference
+does (:131-132; the first callback of a step runs the batch, the others return
+after a counter comparison); `batched=False` keeps the reference's
+one-view-per-prim flow (still one fused launch per prim instead of ~40).
 
 The simulator is reached only through the small `SimHost` protocol below, so
 the class runs under Kit (`KitHost`, imports omni/pxr lazily) and under the
@@ -32,7 +35,7 @@ import numpy as np
 import torch
 
 from . import config as cfg
-from .engine import HydroEngine
+from .engine import HydroEngine, HydroError
 
 log = logging.getLogger("silver2_isaacsim_amd")
 
@@ -64,37 +67,75 @@ class SimHost(Protocol):
     def make_rigid_view(self, prim_paths: Sequence[str], name: str) -> BodyView: ...
     def subscribe_physics_step(self, callback: Callable[[float], None]) -> Any: ...
     def config_path(self) -> str | None: ...
+    # optional (looked up with getattr): what else the reference's lifecycle touches in Kit
+    #   ensure_simulation_context()      SimulationContext(backend="torch", device=...)        (:50-51)
+    #   request_property_rebuild()       omni.kit.window.property.get_window().request_rebuild()  (:70, :126)
+    #   unsubscribe_physics_step(token)  release a subscription (Kit: dropping the token does it)
 
 
 # --------------------------------------------------------------------------
 # batching registry
 # --------------------------------------------------------------------------
+_warned_non_torch = False
+
+
+def _as_device_tensor(x, dev: torch.device) -> torch.Tensor:
+    """What a body view handed out -> contiguous float32 tensor on `dev`.  A view created without the torch backend
+    (no `SimulationContext(backend="torch", ...)`, hydrodynamics_behavior.py:50-51) hands out NumPy arrays: they are
+    converted - and copied to the device every step - with ONE warning per process, never skipped silently."""
+    global _warned_non_torch
+    if not torch.is_tensor(x):
+        if not _warned_non_torch:
+            _warned_non_torch = True
+            log.warning("[Hydro] the body view returned %s, not torch tensors: is the simulation context running with "
+                        "backend='torch'? Converting and copying to %s every physics step (slow, but correct).",
+                        type(x).__name__, dev)
+        x = torch.as_tensor(np.ascontiguousarray(x))
+    return x.to(dev, torch.float32).contiguous()
+
+
 class _AosStepper:
     """`hydro_step_wrench_aos` on what a body view hands out, prepared once per set of device buffers.
 
     A simulator's tensor API returns views of the SAME device buffers every physics step, so the launch is prepared
     once (engine.prepare_step_wrench_aos: arguments validated, ctypes values built) and re-issued while the three
-    pointers stay the same; another device, dtype or layout, or new buffers, go through the conversions and a fresh
-    preparation.  Returns the positions tensor the kernel read (for apply_forces_and_torques_at_pos)."""
+    pointers stay the same; another device, dtype or layout, NumPy arrays, or new buffers go through the conversions
+    and a fresh preparation (the general case: nothing pins `get_world_poses(clone=False)` to stable buffers).
+
+    Two halves, because only the first one is a STATE FETCH whose failure skips the step (:177-192):
+    `accept(...)` takes the view's tensors (conversions may raise the fetch errors), `launch(dt)` runs the kernel -
+    engine errors (HYDRO_E_ARG, HYDRO_E_LAUNCH, a closed engine) propagate to the caller like any exception of the
+    reference's calculator call (:205-209, outside its try)."""
 
     def __init__(self, engine: HydroEngine, force: torch.Tensor, torque: torch.Tensor):
         self.engine, self.force, self.torque = engine, force, torque
         self._key = None
         self._step = None
+        self.prepared = 0                   # how many times the launch had to be prepared (1 for a stable-buffer host)
 
-    def __call__(self, positions, orientations, velocities, dt: float):
-        key = (positions.data_ptr(), orientations.data_ptr(), velocities.data_ptr(), velocities.shape[0])
-        if key != self._key:
-            dev = self.engine.device
-            positions = positions.to(dev, torch.float32).contiguous()
-            orientations = orientations.to(dev, torch.float32).contiguous()
-            velocities = velocities.to(dev, torch.float32).contiguous()
-            self._step = self.engine.prepare_step_wrench_aos(positions, orientations, velocities,
-                                                             forces=self.force, torques=self.torque)
-            same = key == (positions.data_ptr(), orientations.data_ptr(), velocities.data_ptr(), velocities.shape[0])
-            self._key = key if same else None               # converted copies are good for this step only
+    def accept(self, positions, orientations, velocities) -> torch.Tensor:
+        """Returns the positions tensor the kernel will read (for apply_forces_and_torques_at_pos)."""
+        if torch.is_tensor(positions) and torch.is_tensor(orientations) and torch.is_tensor(velocities):
+            key = (positions.data_ptr(), orientations.data_ptr(), velocities.data_ptr(), velocities.shape[0])
+            if key == self._key:
+                return positions
+        else:
+            key = None
+        dev = self.engine.device
+        p, q, v = (_as_device_tensor(positions, dev), _as_device_tensor(orientations, dev), _as_device_tensor(velocities, dev))
+        self._step = self.engine.prepare_step_wrench_aos(p, q, v, forces=self.force, torques=self.torque)
+        self.prepared += 1
+        same = key is not None and key == (p.data_ptr(), q.data_ptr(), v.data_ptr(), v.shape[0])
+        self._key = key if same else None               # converted copies are good for this step only
+        return p
+
+    def launch(self, dt: float) -> None:
         self._step(dt)
-        return positions
+
+    def __call__(self, positions, orientations, velocities, dt: float) -> torch.Tensor:
+        p = self.accept(positions, orientations, velocities)
+        self.launch(dt)
+        return p
 
 
 class _Group:
@@ -110,6 +151,31 @@ class _Group:
         self.force = self.torque = None
         self._stepper: _AosStepper | None = None
         self.batches = 0                    # physics steps for which the batch has run (see EngineRegistry.on_step)
+        self.subscription = None            # the group's own physics-step subscription (scene mode)
+        self.scene_members = 0              # members that rely on it
+        self._engine_error_logged = False
+
+    # scene mode: ONE subscription for the whole group -------------------------------------------------------
+    def subscribe(self) -> Any:
+        if self.subscription is None:
+            self.subscription = self.host.subscribe_physics_step(self._on_physics_step)
+        self.scene_members += 1
+        return self.subscription
+
+    def unsubscribe(self) -> None:
+        self.scene_members -= 1
+        if self.scene_members <= 0 and self.subscription is not None:
+            release = getattr(self.host, "unsubscribe_physics_step", None)
+            if release is not None:
+                release(self.subscription)
+            self.subscription = None        # under Kit dropping the token IS the unsubscribe
+            self.scene_members = 0
+
+    def _on_physics_step(self, delta_time: float) -> None:
+        if delta_time <= 1e-6:              # the reference's guard (:139)
+            return
+        self.batches += 1
+        self.step(delta_time)
 
     def rebuild(self) -> None:
         if self.engine is not None:
@@ -118,7 +184,8 @@ class _Group:
         self.view = self.host.make_rigid_view(paths, "hydro_view_batched")
         self.view.initialize()
         masses = self.view.get_masses(clone=False)
-        masses = masses.detach().to("cpu", torch.float32).numpy().reshape(-1)
+        masses = (masses.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(masses)
+                  else np.asarray(masses, dtype=np.float32)).reshape(-1)
         rows = np.stack([m._param_row(masses[i]) for i, m in enumerate(self.members)], axis=0)
         self.engine = HydroEngine(len(paths), self.host.device, self.rho, self.g)
         self.engine.set_params(rows)
@@ -134,19 +201,29 @@ class _Group:
             self.rebuild()
         if self.view is None or not self.view.is_valid():
             return
-        try:
+        try:                                            # the state fetch, and only it (:177-192): failures skip the step
             positions, orientations = self.view.get_world_poses(clone=False)
             velocities = self.view.get_velocities(clone=False)
             if velocities is None or velocities.shape[0] == 0:
                 return
-            positions = self._stepper(positions, orientations, velocities, dt)
+            positions = self._stepper.accept(positions, orientations, velocities)
         except _STATE_FETCH_ERRORS:
             return
+        try:
+            self._stepper.launch(dt)                    # engine errors are NOT a fetch failure: they surface
+        except HydroError as e:
+            if not self._engine_error_logged:
+                self._engine_error_logged = True
+                log.error("[Hydro] the force engine refused the step for %d prims (%s); no hydrodynamic wrench is applied", len(self.members), e)
+            raise
         self.view.apply_forces_and_torques_at_pos(forces=self.force, torques=self.torque,
                                                   positions=positions, is_global=True)
         self.steps += 1
 
     def close(self) -> None:
+        if self.subscription is not None:
+            self.scene_members = 1
+            self.unsubscribe()
         if self.engine is not None:
             self.engine.close()
         self.engine = self.view = None
@@ -214,11 +291,15 @@ class HydrodynamicsBehavior:
     # (added-mass rotation; include/hydro.h HYDRO_SEM_WARP).  Override in the scripted subclass.
     SEMANTICS = "numba"
 
-    def __init__(self, prim=None, host: SimHost | None = None, batched: bool = True):
+    def __init__(self, prim=None, host: SimHost | None = None, batched: bool | str = True):
         if prim is not None:
             self.prim = prim
+        if batched not in (True, False, "scene", "callbacks"):
+            raise ValueError("batched must be True / 'scene', 'callbacks' or False")
         self._host = host
-        self._batched = batched
+        self._batched = bool(batched)
+        # True / "scene": the group holds ONE physics-step subscription; "callbacks": one per prim, as the reference
+        self._scene_mode = batched in (True, "scene")
         self._group: _Group | None = None
         self._engine: HydroEngine | None = None
         self._callbacks = 0                 # physics-step callbacks received since the group last changed
@@ -228,12 +309,21 @@ class HydrodynamicsBehavior:
         if self._host is None:
             self._host = KitHost()
         self._device = self._host.device
+        # the simulation context with the torch backend (:50-51): without it a RigidPrimView hands out NumPy arrays
+        ensure = getattr(self._host, "ensure_simulation_context", None)
+        self._sim_context = ensure() if ensure is not None else None
         self._hydro_calculator = None
         self._rigid_prim_view = None
         self._physx_subscription = None
         self._prim_path = self._host.prim_path(self.prim)
         self._host.create_exposed_variables(self.prim, self.VARIABLES_TO_EXPOSE)
         self._apply_json_config()
+        self._request_property_rebuild()                                   # (:70)
+
+    def _request_property_rebuild(self):
+        rebuild = getattr(self._host, "request_property_rebuild", None)
+        if rebuild is not None:
+            rebuild()
 
     def _apply_json_config(self):
         """globals, then the first `parts` key contained in the lower-cased prim name
@@ -254,10 +344,15 @@ class HydrodynamicsBehavior:
 
     def on_destroy(self):
         self._reset()
-        self._host.remove_exposed_variables(self.prim, self.VARIABLES_TO_EXPOSE)
+        if self._host.remove_exposed_variables(self.prim, self.VARIABLES_TO_EXPOSE) is not False:
+            self._request_property_rebuild()                               # (:124-126)
 
     def on_play(self):
         self._setup()
+        if self._batched and self._scene_mode:
+            # one subscription per GROUP: host time per physics step does not grow with the number of prims
+            self._physx_subscription = self._group.subscribe() if self._group is not None else None
+            return
         self._physx_subscription = self._host.subscribe_physics_step(self._on_physics_step)
 
     def on_stop(self):
@@ -268,7 +363,9 @@ class HydrodynamicsBehavior:
         if delta_time <= 1e-6:
             return
         if self._batched:
-            if self._group is not None:
+            # "callbacks" mode (or a host that calls the per-prim callback itself); in scene mode the group's own
+            # subscription drives the step and this method is not subscribed
+            if self._group is not None and not (self._scene_mode and self._group.subscription is not None):
                 EngineRegistry.on_step(self._group, self, delta_time)
             return
         if self._rigid_prim_view is None or not self._rigid_prim_view.is_valid():
@@ -314,18 +411,31 @@ class HydrodynamicsBehavior:
             full_velocities = self._rigid_prim_view.get_velocities(clone=False)
             if full_velocities is None or full_velocities.shape[0] == 0:
                 return
-            # quaternion reorder, finite-difference acceleration, model, lever arms, sum and clamp
-            # (hydrodynamics_behavior.py:194-226) are one kernel; the previous velocity lives in the engine
-            positions = self._stepper(positions, orientations, full_velocities, delta_time)
-        except _STATE_FETCH_ERRORS:
+            positions = self._stepper.accept(positions, orientations, full_velocities)
+        except _STATE_FETCH_ERRORS:                                        # the state fetch, and only it (:177-192)
             return
+        # quaternion reorder, finite-difference acceleration, model, lever arms, sum and clamp
+        # (hydrodynamics_behavior.py:194-226) are one kernel; the previous velocity lives in the engine.  Engine errors
+        # propagate, as an exception of the reference's calculator call (:205-209) would.
+        self._stepper.launch(delta_time)
         self._rigid_prim_view.apply_forces_and_torques_at_pos(
             forces=self._force, torques=self._torque, positions=positions, is_global=True)
 
     def _reset(self):
         if self._group is not None:
+            if self._physx_subscription is not None:
+                if self._scene_mode:
+                    self._group.unsubscribe()
+                else:
+                    release = getattr(self._host, "unsubscribe_physics_step", None)
+                    if release is not None:
+                        release(self._physx_subscription)
             REGISTRY.unregister(self)
             self._group = None
+        elif self._physx_subscription is not None:
+            release = getattr(self._host, "unsubscribe_physics_step", None)
+            if release is not None:
+                release(self._physx_subscription)
         if self._engine is not None:
             self._engine.close()
             self._engine = None
@@ -344,6 +454,26 @@ class KitHost:
     def __init__(self, device: str = "cuda:0", config_dir: str | None = None):
         self.device = device
         self._config_dir = config_dir or os.path.dirname(os.path.abspath(__file__))
+        self._sim_context = None
+
+    def ensure_simulation_context(self):
+        """`SimulationContext(backend="torch", device=...)` (hydrodynamics_behavior.py:50-51): the tensor API then hands
+        out torch tensors on `device`; without it `RigidPrimView` returns NumPy arrays.  SimulationContext is a
+        singleton in Isaac Sim, so calling this once per behavior instance is what the reference does too."""
+        if self._sim_context is None:
+            from omni.isaac.core.simulation_context import SimulationContext    # type: ignore
+            self._sim_context = SimulationContext(backend="torch", device=self.device)
+        return self._sim_context
+
+    def request_property_rebuild(self):
+        """Refresh the Property window after exposed variables appeared or went (:70, :126)."""
+        import omni.kit.window.property                                      # type: ignore
+        omni.kit.window.property.get_window().request_rebuild()
+
+    def unsubscribe_physics_step(self, token):
+        unsub = getattr(token, "unsubscribe", None)                          # carb subscriptions release on drop as well
+        if unsub is not None:
+            unsub()
 
     def _utils(self):
         from isaacsim.replicator.behavior.utils import behavior_utils    # type: ignore
@@ -359,6 +489,8 @@ class KitHost:
         typed = [dict(v, attr_type=Sdf.ValueTypeNames.Float) for v in variables]
         if self._utils().check_if_exposed_variables_should_be_removed(prim, __file__):
             self._utils().remove_exposed_variables(prim, cfg.EXPOSED_ATTR_NS, cfg.BEHAVIOR_NS, typed)
+            return True
+        return False                                                          # kept: no Property-window rebuild (:124-126)
 
     def get_exposed_variable(self, prim, full_attr_name):
         return self._utils().get_exposed_variable(prim, full_attr_name)

@@ -159,8 +159,14 @@ struct Body {
 // (hydrodynamics_config.json:2-5 "globals"), doubles as the reference passes Python floats.
 // `warp` (uniform over a launch) selects the semantics of the reference's Warp twin where it differs from the Numba
 // path (include/hydro.h HYDRO_SEM_WARP - PARITY UNPINNED for that mode); the default is Numba.
-HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, double bx, double by, double bz,
-                         double rho, double g, bool warp = false)
+//
+// `late(anchor, ...)` supplies what only the LAST block (A10, added mass) consumes: the six accelerations and the two
+// added-mass coefficients.  It is called right where they are needed, with a value computed in the middle of the body
+// (`anchor`): a kernel may tie its loads of those inputs to it so that they are issued late and their registers are
+// not live through the first two thirds of the arithmetic (hydro_kernels.hip, LATE template argument).  The results
+// do not depend on where the inputs come from.
+template <class Late>
+HYDRO_FN Body solve_body_with(const BodyIn& b, Late&& late, double rho, double g, bool warp)
 {
     Body o;
     // ---- A1: rotation matrix (numba_hydrodynamics.py:14-49), the quaternion used as given (N7) ----
@@ -282,6 +288,9 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
 
     // ---- A10: added mass (:220-253; diagonal of numba_hydrodynamics_wrapper.py:101-112) ----
     {
+        double ax, ay, az, bx, by, bz;                                          // world-frame accelerations
+        float am_lin, am_ang;
+        late(area, ax, ay, az, bx, by, bz, am_lin, am_ang);
         double alx, aly, alz, blx, bly, blz;                                    // accelerations in the "local" frame
         if (warp) {                                                             // N3: quat_rotate = R (warp_hydrodynamics.py:216-217)
             alx = r00 * ax + r01 * ay + r02 * az; aly = r10 * ax + r11 * ay + r12 * az; alz = r20 * ax + r21 * ay + r22 * az;
@@ -291,13 +300,23 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
             blx = r00 * bx + r10 * by + r20 * bz; bly = r01 * bx + r11 * by + r21 * bz; blz = r02 * bx + r12 * by + r22 * bz;
         }
         const double rv = vol * rho;
-        const double kf = -(rv * (double)b.am_lin) * ratio, kt = -(rv * (double)b.am_ang) * ratio;
+        const double kf = -(rv * (double)am_lin) * ratio, kt = -(rv * (double)am_ang) * ratio;
         const double glx = kf * alx, gly = kf * aly, glz = kf * alz;
         const double tlx = kt * (dy * dy + dz * dz) * blx, tly = kt * (dx * dx + dz * dz) * bly, tlz = kt * (dx * dx + dy * dy) * blz;
         o.am_fx = r00 * glx + r01 * gly + r02 * glz; o.am_fy = r10 * glx + r11 * gly + r12 * glz; o.am_fz = r20 * glx + r21 * gly + r22 * glz;
         o.am_tx = r00 * tlx + r01 * tly + r02 * tlz; o.am_ty = r10 * tlx + r11 * tly + r12 * tlz; o.am_tz = r20 * tlx + r21 * tly + r22 * tlz;
     }
     return o;
+}
+
+// A1-A11 with the accelerations and the added-mass coefficients at hand (component mode, host instantiation).
+HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, double bx, double by, double bz,
+                         double rho, double g, bool warp = false)
+{
+    return solve_body_with(b, [&](double, double& oax, double& oay, double& oaz, double& obx, double& oby, double& obz,
+                                  float& am_lin, float& am_ang) {
+        oax = ax; oay = ay; oaz = az; obx = bx; oby = by; obz = bz; am_lin = b.am_lin; am_ang = b.am_ang;
+    }, rho, g, warp);
 }
 
 struct Wrench {
@@ -336,6 +355,23 @@ HYDRO_FN Wrench solve_wrench(const BodyIn& b, const float (&pv)[6], float mass, 
     return assemble_wrench(solve_body(b, ax, ay, az, bx, by, bz, rho, g, warp), mass);
 }
 
+// The same with the late inputs fetched by the caller's `load(anchor, pv, am_lin, am_ang, mass)` at the point of use
+// (see solve_body_with): the previous-step velocity, the two added-mass coefficients and the mass are what the last
+// third of the evaluation needs and nothing before it does.  Same expressions, same bits as solve_wrench.
+template <class LateLoad>
+HYDRO_FN Wrench solve_wrench_late(const BodyIn& b, LateLoad&& load, double rho, double g, double inv_dt, bool warp)
+{
+    float mass = 0.0f;
+    const Body o = solve_body_with(b, [&](double anchor, double& ax, double& ay, double& az, double& bx, double& by, double& bz,
+                                          float& am_lin, float& am_ang) {
+        float pv[6];
+        load(anchor, pv, am_lin, am_ang, mass);
+        ax = ((double)b.vx - (double)pv[0]) * inv_dt; ay = ((double)b.vy - (double)pv[1]) * inv_dt; az = ((double)b.vz - (double)pv[2]) * inv_dt;
+        bx = ((double)b.wx - (double)pv[3]) * inv_dt; by = ((double)b.wy - (double)pv[4]) * inv_dt; bz = ((double)b.wz - (double)pv[5]) * inv_dt;
+    }, rho, g, warp);
+    return assemble_wrench(o, mass);
+}
+
 // The calculator surface (calculate_hydrodynamic_forces, numba_hydrodynamics_wrapper.py:34-53): the eight vectors
 // and the ratio as fp32, world-space centres.  A dry body returns zeros for everything, centres included (Numba,
 // :277-279); the Warp twin reports cob = cop = the position, or the mean of whatever keypoints are wet (N6,
@@ -365,6 +401,34 @@ HYDRO_FN Components round_components(const Body& o, const BodyIn& b, bool warp)
         c.v[7][a] = centres ? (float)(p[a] + cp[a]) : 0.0f;
     }
     return c;
+}
+
+// Kinetic energy of one body (new functionality named by BASELINE.json north_star, absent from the reference:
+// SURVEY.md 8e): translational 1/2 m |v|^2 and, with the box inertia I = m/12 diag(dy^2+dz^2, dx^2+dz^2, dx^2+dy^2) in
+// the body frame, rotational 1/2 w_b.I.w_b with w_b = R^T w.  fp64 from the fp32 state; the rotation matrix is
+// written exactly as in solve_body_with, so a kernel that evaluates both shares it.
+HYDRO_FN void kinetic_energy(float fqx, float fqy, float fqz, float fqw, float fvx, float fvy, float fvz,
+                             float fwx, float fwy, float fwz, float fdx, float fdy, float fdz, float fmass,
+                             bool rotational, double& lin, double& rot)
+{
+    const double m = fmass;
+    const double vx = fvx, vy = fvy, vz = fvz;
+    lin = 0.5 * m * (vx * vx + vy * vy + vz * vz);
+    rot = 0.0;
+    if (rotational) {
+        const double qx = fqx, qy = fqy, qz = fqz, qw = fqw;
+        const double x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+        const double xx = qx * x2, yy = qy * y2, zz = qz * z2;
+        const double sx = qw * x2, sy = qw * y2, sz = qw * z2;
+        const double r00 = 1.0 - (yy + zz), r01 = __builtin_fma(qx, y2, -sz), r02 = __builtin_fma(qx, z2, sy);
+        const double r10 = __builtin_fma(qx, y2, sz), r11 = 1.0 - (xx + zz), r12 = __builtin_fma(qy, z2, -sx);
+        const double r20 = __builtin_fma(qx, z2, -sy), r21 = __builtin_fma(qy, z2, sx), r22 = 1.0 - (xx + yy);
+        const double wx = fwx, wy = fwy, wz = fwz;
+        const double bx = r00 * wx + r10 * wy + r20 * wz, by = r01 * wx + r11 * wy + r21 * wz, bz = r02 * wx + r12 * wy + r22 * wz;
+        const double dx = fdx, dy = fdy, dz = fdz;
+        const double k = m / 12.0;
+        rot = 0.5 * k * ((dy * dy + dz * dz) * (bx * bx) + (dx * dx + dz * dz) * (by * by) + (dx * dx + dy * dy) * (bz * bz));
+    }
 }
 
 }  // namespace hydro

@@ -1,7 +1,9 @@
 // gfx950 (MI355X / CDNA4) kernels and C ABI of libhydro.so - see include/hydro.h.
 //
-// Every kernel is elementwise per rigid body and HBM-bound (about 600 VALU instructions, two thirds of them fp64 -
-// hydro_body.h says why - against 122-144 B per body-step): no MFMA anywhere.  What matters is
+// Every kernel is elementwise per rigid body: about 520 VALU instructions, two thirds of them fp64 (hydro_body.h says
+// why), against 122-144 B per body-step - no MFMA anywhere.  HBM is the larger of the two bounds and the arithmetic
+// is not far behind (memory-only probe 21.9 us, compute-only probe 17.4 us, kernel 23-25 us at 1 M bodies:
+// scripts/probes.py).  What matters is
 //   * layouts in which each wave-instruction reads one contiguous 256-B run of one field
 //     (plain SoA) and - better - in which the ~28 runs a wavefront needs form three contiguous
 //     records (tiled SoA, the native layout): DRAM pages are consumed whole;
@@ -9,9 +11,10 @@
 //     set in flight at once (single-pass kernels, latency hidden by 4 waves per SIMD: ~100 VGPRs);
 //   * non-temporal accesses for scenes larger than the caches: every byte is touched once per step;
 //   * nothing re-read and nothing written but the wrench (24 B per body).
-// The array-of-structs entry points (the simulator's tensor layout) stage the transposition
-// through LDS; the kinetic-energy reduction uses wave64 shuffles, LDS across the block's four
-// waves and a fixed-order second stage.
+// The array-of-structs entry (the simulator's tensor layout) reads and writes one row per lane with 12- and 16-byte
+// accesses (LDS staging of the transposition was measured and lost: DESIGN.md section 5); the kinetic-energy
+// reduction - stand-alone, or fused into the wrench / step kernels for the bodies already in registers - uses wave64
+// shuffles, LDS across the block's four waves and a fixed-order second stage.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -26,11 +29,25 @@
 #ifndef HYDRO_AB_LDS_WRENCH
 #define HYDRO_AB_LDS_WRENCH 0        // A/B knob, see wrench_tiled_kernel
 #endif
+#ifndef HYDRO_AB_AOS_LDS              // A/B knob: hydro_step_wrench_aos through the LDS-staged wrench_aos_kernel (measured slower)
+#define HYDRO_AB_AOS_LDS 0
+#endif
+#ifndef HYDRO_AB_TILED_LDS            // A/B knob: hydro_step_wrench_tiled through wrench_tiled_lds_kernel (LDS-DMA staging)
+#define HYDRO_AB_TILED_LDS 0
+#endif
+#ifndef HYDRO_AB_TILED_WAVES         // A/B knob: minimum resident waves per SIMD asked of the tiled wrench kernel (0 = what it needs)
+#define HYDRO_AB_TILED_WAVES 0
+#endif
+#if HYDRO_AB_TILED_WAVES
+#define HYDRO_TILED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(HYDRO_AB_TILED_WAVES)))
+#else
+#define HYDRO_TILED_OCC_ATTR
+#endif
 
 namespace {
 
 constexpr int kBlock = 256;                // 4 waves of 64 lanes
-constexpr int kKeBlocks = 1024;            // first-stage partials of the KE reduction
+constexpr int kKeFinalBlock = 1024;        // threads of the second stage of the kinetic-energy reduction
 // Occupancy: the fp64 body needs 98-132 VGPRs depending on the kernel around it and on the build flags, i.e. 3-4 waves
 // per SIMD.  Forcing a number (__launch_bounds__' second argument) made the compiler spill 2-4 registers on the path
 // every wave runs when the kernel needed 130: measured 28.2 vs 24.0 us at 1 M bodies - the
@@ -136,6 +153,32 @@ __device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t
     else return *at<float>(p, i * 4u);
 }
 
+
+// --------------------------------------------------------------------------
+// block-level reduction of the kinetic-energy pair (used by the stand-alone first stage and by the wrench / step
+// kernels that sample the energy of the bodies they hold: see "kinetic energy" below)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+// every thread of a 256-thread block calls this (idle lanes with zeros); partials = [2][stride]
+__device__ __forceinline__ void ke_block_partial(double lin, double rot, double* __restrict__ partials, uint32_t stride)
+{
+    __shared__ double red[2][kBlock / 64];
+    lin = wave_sum(lin);
+    rot = wave_sum(rot);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = lin; red[1][wave] = rot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        partials[stride + blockIdx.x] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+}
 
 // --------------------------------------------------------------------------
 // kernel arguments (passed by value in the kernarg segment: pointers land in SGPRs)
@@ -300,52 +343,168 @@ __device__ __forceinline__ void load_tile_records(const TiledArgs& a, uint32_t t
 // the first 16 dwords: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py) those arrive in SGPRs with the wave
 // (gfx950 kernarg preload) instead of behind three dependent scalar-memory round trips (~0.3 us per wave start,
 // exposed in the ramp of every launch and in all of a 2.6 us launch).  A struct passed by value cannot be preloaded.
-template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT>
-__global__ void __launch_bounds__(BLOCK) wrench_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
+// KE = true (BLOCK 256 only): the kernel also samples the kinetic energy of the bodies it holds - the state it READS,
+// i.e. the state after the previous step - and leaves one fp64 pair per block in `ke_partials` ([2][ke_stride]) for
+// the fixed-order second stage: no second pass over the state ("reduced in-kernel").
+template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT, bool KE = false>
+__global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
                                                              uint32_t st_stride, uint32_t pv_stride, uint32_t out_stride, uint32_t pvo_stride,
-                                                             uint32_t n, int warp, double rho, double g, double inv_dt)
+                                                             uint32_t n, int warp, double rho, double g, double inv_dt,
+                                                             double* ke_partials, uint32_t ke_stride, int ke_rotational)
 {
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pv_out; a.pvo_stride = pvo_stride;
     a.prm = k_prm; a.out = k_out; a.out_stride = out_stride; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = warp; a.n = n;
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t tile = i >> 6, lane = i & 63u;
-    // tile < 2^24 and strides < 2^24 (checked on the host): full-rate 24-bit multiplies
-    const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
-    const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
-    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-    load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
-#if HYDRO_AB_LDS_WRENCH
-    // A/B knob ("LDS staging"): the wave's 6 x 256 B of wrench go through a wave-private LDS slice
-    // and leave as 1.5 sixteen-byte stores per lane instead of six four-byte ones.  Measured: no faster - the
-    // four-byte stores of a wave already cover whole 256-B runs.
-    {
-        __shared__ __attribute__((aligned(16))) float stage[BLOCK / 64][6 * 64];
-        using f4 = float __attribute__((ext_vector_type(4)));
-        float* sl = stage[threadIdx.x >> 6];
-        sl[lane] = w.fx; sl[64 + lane] = w.fy; sl[128 + lane] = w.fz; sl[192 + lane] = w.tx; sl[256 + lane] = w.ty; sl[320 + lane] = w.tz;
-        wave_lds_fence();
-        f4* dst = reinterpret_cast<f4*>(const_cast<float*>(a.out) + (size_t)__umul24(tile, a.out_stride));
-        stg<NT>(dst + lane, reinterpret_cast<const f4*>(sl)[lane]);
-        if (lane < 32u) stg<NT>(dst + 64 + lane, reinterpret_cast<const f4*>(sl)[64 + lane]);
+    if constexpr (!KE) {
+        if (i >= a.n) return;
     }
+    double ke_lin = 0.0, ke_rot = 0.0;
+    if (!KE || i < a.n) {                       // (KE: no early return - every thread reaches the block reduction)
+        const uint32_t tile = i >> 6, lane = i & 63u;
+        // tile < 2^24 and strides < 2^24 (checked on the host): full-rate 24-bit multiplies
+        const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
+        const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
+        float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
+        load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+        const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+        if constexpr (KE)
+            hydro::kinetic_energy(s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], d[0], d[1], d[2], mass,
+                                  ke_rotational != 0, ke_lin, ke_rot);
+#if HYDRO_AB_LDS_WRENCH
+        // A/B knob ("LDS staging"): the wave's 6 x 256 B of wrench go through a wave-private LDS slice
+        // and leave as 1.5 sixteen-byte stores per lane instead of six four-byte ones.  Measured: no faster - the
+        // four-byte stores of a wave already cover whole 256-B runs.
+        {
+            __shared__ __attribute__((aligned(16))) float stage[BLOCK / 64][6 * 64];
+            using f4 = float __attribute__((ext_vector_type(4)));
+            float* sl = stage[threadIdx.x >> 6];
+            sl[lane] = w.fx; sl[64 + lane] = w.fy; sl[128 + lane] = w.fz; sl[192 + lane] = w.tx; sl[256 + lane] = w.ty; sl[320 + lane] = w.tz;
+            wave_lds_fence();
+            f4* dst = reinterpret_cast<f4*>(const_cast<float*>(a.out) + (size_t)__umul24(tile, a.out_stride));
+            stg<NT>(dst + lane, reinterpret_cast<const f4*>(sl)[lane]);
+            if (lane < 32u) stg<NT>(dst + 64 + lane, reinterpret_cast<const f4*>(sl)[64 + lane]);
+        }
 #else
-    const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
-    stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
-    stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
+        const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
+        stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
+        stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
 #endif
-    if constexpr (WRITE_PREV) {
-        const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
+        if constexpr (WRITE_PREV) {
+            const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo, f * 256u), s[7 + f]);
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo, f * 256u), s[7 + f]);
+        }
+    }
+    if constexpr (KE) {
+        static_assert(BLOCK == kBlock, "the kinetic-energy partials are one per 256 bodies");
+        ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
     }
 }
 
-// SoA parameters [11][stride] -> tiled records (once per hydro_set_params_*)
-__global__ void __launch_bounds__(kBlock) params_to_tiled_kernel(const float* __restrict__ soa, int64_t stride, const __half* __restrict__ coef16,
-                                                                 float* __restrict__ tiled, int half, uint32_t n_pad, uint32_t n)
+#if HYDRO_AB_TILED_LDS
+// --------------------------------------------------------------------------
+// A/B arm ("LDS-DMA staging"; not compiled into the product): the same kernel with the inputs
+// STAGED IN LDS by direct global->LDS loads (gfx950 LDS-DMA,
+// global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR destination).
+//
+// A wavefront's three records are contiguous in the tiled layout, so six instructions bring in what 28 four- and
+// two-byte loads bring in above - state fields 2..12 (2 816 B: p_x, p_y are skipped), previous velocity (1 536 B),
+// parameters (1 920 B with fp16 coefficients, 2 816 B with fp32 ones) - into the wave's PRIVATE LDS slice, in the
+// record's own order (the LDS image of an LDS-DMA is lane-linear: wave-uniform base + lane * 16, exactly a record).
+// While the loads are in flight they hold no registers; each input is picked up with a ds_read_b32 where the
+// arithmetic first needs it, so the kernel allocates fewer VGPRs and more wavefronts are resident to cover HBM
+// latency (6.1 KiB of LDS per wave: 25 KiB per block, six blocks fit a CU's 160 KiB).  Nothing is shared between
+// waves: the only synchronisation is the wave's own s_waitcnt vmcnt(0) before its first LDS read.
+// --------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ void glds16(const void* gsrc, float* lds_dst)
+{
+    __builtin_amdgcn_global_load_lds(gsrc, lds_dst, 16, 0, NT ? 2 : 0);
+}
+
+template <bool HALF> constexpr uint32_t lds_prm_bytes() { return HALF ? kPrmTileF16 * 4u : kPrmTileF32 * 4u; }
+constexpr uint32_t kLdsStateFloats = 11 * 64, kLdsPrevFloats = 6 * 64;
+template <bool HALF> constexpr uint32_t lds_wave_floats() { return kLdsStateFloats + kLdsPrevFloats + lds_prm_bytes<HALF>() / 4u; }
+
+#ifndef HYDRO_AB_LDS_WAVES
+#define HYDRO_AB_LDS_WAVES 0
+#endif
+#if HYDRO_AB_LDS_WAVES
+#define HYDRO_LDS_OCC_ATTR __attribute__((amdgpu_waves_per_eu(HYDRO_AB_LDS_WAVES)))
+#else
+#define HYDRO_LDS_OCC_ATTR
+#endif
+
+template <bool HALF, bool WRITE_PREV, bool NT>
+__global__ void __launch_bounds__(kBlock) HYDRO_LDS_OCC_ATTR wrench_tiled_lds_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
+                                                                  uint32_t st_stride, uint32_t pv_stride, uint32_t out_stride, uint32_t pvo_stride,
+                                                                  uint32_t n, int warp, double rho, double g, double inv_dt)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[kBlock / 64][lds_wave_floats<HALF>()];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * (kBlock / 64) + wave;
+    if (tile * 64u >= n) return;                                    // whole wave idle (no workgroup barrier anywhere below)
+    float* L = lds_all[wave];
+    float* Ls = L;                                                  // state fields 2..12
+    float* Lp = L + kLdsStateFloats;                                // previous velocity
+    float* Lq = Lp + kLdsPrevFloats;                                // parameters
+    // every buffer holds whole tiles (the last one padded), so a wave always moves whole records
+    const char* gs = reinterpret_cast<const char*>(k_st) + (size_t)__umul24(tile, st_stride) * 4u + 512u + lane * 16u;
+    const char* gp = reinterpret_cast<const char*>(k_pv) + (size_t)__umul24(tile, pv_stride) * 4u + lane * 16u;
+    const char* gq = reinterpret_cast<const char*>(k_prm) + (size_t)tile * lds_prm_bytes<HALF>() + lane * 16u;
+    glds16<NT>(gs, Ls);
+    glds16<NT>(gs + 1024, Ls + 256);
+    if (lane < 48u) glds16<NT>(gs + 2048, Ls + 512);
+    glds16<NT>(gp, Lp);
+    if (lane < 32u) glds16<NT>(gp + 1024, Lp + 256);
+    glds16<NT>(gq, Lq);
+    if constexpr (HALF) {
+        if (lane < 56u) glds16<NT>(gq + 1024, Lq + 256);
+    } else {
+        glds16<NT>(gq + 1024, Lq + 256);
+        if (lane < 48u) glds16<NT>(gq + 2048, Lq + 512);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's LDS-DMA has landed (its own reads need no barrier)
+    const uint32_t i = tile * 64u + lane;
+    if (i >= n) return;
+    hydro::BodyIn b;
+    b.px = 0.0f; b.py = 0.0f;                                       // never used by the wrench
+    b.pz = Ls[lane];
+    b.qx = Ls[64 + lane]; b.qy = Ls[128 + lane]; b.qz = Ls[192 + lane]; b.qw = Ls[256 + lane];
+    b.vx = Ls[320 + lane]; b.vy = Ls[384 + lane]; b.vz = Ls[448 + lane];
+    b.wx = Ls[512 + lane]; b.wy = Ls[576 + lane]; b.wz = Ls[640 + lane];
+    float pv[HYDRO_PREV_FIELDS], mass;
+#pragma unroll
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = Lp[f * 64 + lane];
+    b.dimx = Lq[lane]; b.dimy = Lq[64 + lane]; b.dimz = Lq[128 + lane];
+    if constexpr (HALF) {
+        mass = Lq[192 + lane];
+        const unsigned short* H = reinterpret_cast<const unsigned short*>(Lq + 256);
+        b.cd_lin = half_bits_to_float(H[lane]); b.cd_ang = half_bits_to_float(H[64 + lane]);
+        b.damp_lin = half_bits_to_float(H[128 + lane]); b.damp_ang = half_bits_to_float(H[192 + lane]);
+        b.lift = half_bits_to_float(H[256 + lane]); b.am_lin = half_bits_to_float(H[320 + lane]); b.am_ang = half_bits_to_float(H[384 + lane]);
+    } else {
+        b.cd_lin = Lq[192 + lane]; b.cd_ang = Lq[256 + lane]; b.damp_lin = Lq[320 + lane]; b.damp_ang = Lq[384 + lane];
+        b.lift = Lq[448 + lane]; b.am_lin = Lq[512 + lane]; b.am_ang = Lq[576 + lane];
+        mass = Lq[640 + lane];
+    }
+    const hydro::Wrench w = hydro::solve_wrench(b, pv, mass, rho, g, inv_dt, warp != 0);
+    const uint32_t oo = (__umul24(tile, out_stride) + lane) * 4u;
+    stg<NT>(at<float>(k_out, oo), w.fx); stg<NT>(at<float>(k_out, oo, 256u), w.fy); stg<NT>(at<float>(k_out, oo, 512u), w.fz);
+    stg<NT>(at<float>(k_out, oo, 768u), w.tx); stg<NT>(at<float>(k_out, oo, 1024u), w.ty); stg<NT>(at<float>(k_out, oo, 1280u), w.tz);
+    if constexpr (WRITE_PREV) {
+        const uint32_t wo = (__umul24(tile, pvo_stride) + lane) * 4u;
+        stg<NT>(at<float>(k_pv_out, wo), b.vx); stg<NT>(at<float>(k_pv_out, wo, 256u), b.vy); stg<NT>(at<float>(k_pv_out, wo, 512u), b.vz);
+        stg<NT>(at<float>(k_pv_out, wo, 768u), b.wx); stg<NT>(at<float>(k_pv_out, wo, 1024u), b.wy); stg<NT>(at<float>(k_pv_out, wo, 1280u), b.wz);
+    }
+}
+#endif  // HYDRO_AB_TILED_LDS
+
+// Parameters: the caller's 11 field arrays -> the engine's tiled records (once per hydro_set_params_*), and back into
+// plain-SoA copies for the entry points that take plain field pointers (made on their first use only).
+struct ParamPtrs { const float* f[HYDRO_PARAM_FIELDS]; };
+__global__ void __launch_bounds__(kBlock) params_to_tiled_kernel(const ParamPtrs src, float* __restrict__ tiled, int half, uint32_t n_pad, uint32_t n)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_pad) return;
@@ -354,17 +513,41 @@ __global__ void __launch_bounds__(kBlock) params_to_tiled_kernel(const float* __
     // padding lanes of the last tile get a benign unit box so that nothing in it is NaN
     float v[11];
 #pragma unroll
-    for (int f = 0; f < 11; ++f) v[f] = live ? soa[f * stride + i] : (f < 3 || f == 10 ? 1.0f : 0.0f);
+    for (int f = 0; f < 11; ++f) v[f] = live ? src.f[f][i] : (f < 3 || f == 10 ? 1.0f : 0.0f);
     if (half) {
         float* rec = tiled + (size_t)tile * kPrmTileF16;
         rec[0 * 64 + lane] = v[0]; rec[1 * 64 + lane] = v[1]; rec[2 * 64 + lane] = v[2]; rec[3 * 64 + lane] = v[10];
         __half* hrec = reinterpret_cast<__half*>(rec + 256);
 #pragma unroll
-        for (int f = 0; f < 7; ++f) hrec[f * 64 + lane] = live ? coef16[f * stride + i] : __float2half_rn(0.0f);
+        for (int f = 0; f < 7; ++f) hrec[f * 64 + lane] = __float2half_rn(v[3 + f]);
     } else {
         float* rec = tiled + (size_t)tile * kPrmTileF32;
 #pragma unroll
         for (int f = 0; f < 11; ++f) rec[f * 64 + lane] = v[f];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) params_from_tiled_kernel(const float* __restrict__ tiled, int half, float* __restrict__ soa, int64_t stride,
+                                                                   __half* __restrict__ coef16, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    if (half) {
+        const float* rec = tiled + (size_t)tile * kPrmTileF16;
+        soa[0 * stride + i] = rec[lane]; soa[1 * stride + i] = rec[64 + lane]; soa[2 * stride + i] = rec[128 + lane];
+        soa[10 * stride + i] = rec[192 + lane];
+        const __half* hrec = reinterpret_cast<const __half*>(rec + 256);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) {
+            const __half c = hrec[f * 64 + lane];
+            coef16[f * stride + i] = c;
+            soa[(3 + f) * stride + i] = __half2float(c);          // (the fp32 rows then hold what the kernels use)
+        }
+    } else {
+        const float* rec = tiled + (size_t)tile * kPrmTileF32;
+#pragma unroll
+        for (int f = 0; f < 11; ++f) soa[f * stride + i] = rec[f * 64 + lane];
     }
 }
 
@@ -439,14 +622,6 @@ __global__ void __launch_bounds__(kBlock) unpack_wrench_aos_kernel(const UnpackA
     }
 }
 
-// --------------------------------------------------------------------------
-// fused wrench on the simulator's array-of-structs tensors.
-// One block = 256 consecutive bodies.  positions (256x3) and velocities (256x6) are read
-// as whole 16-B chunks (fully coalesced), parked in LDS and picked up per body with
-// conflict-free strides (3 and 6 dwords: odd / 2*odd); orientations are one float4 per
-// lane already.  Forces and torques take the same road back.  Previous velocity is the
-// engine's SoA (read, then overwritten with this step's velocity).
-// --------------------------------------------------------------------------
 struct AosArgs {
     const float* pos;       // (n,3)
     const float* quat;      // (n,4)
@@ -462,6 +637,86 @@ struct AosArgs {
     int64_t n;
 };
 
+// --------------------------------------------------------------------------
+// fused wrench on the simulator's array-of-structs tensors (hydro_step_wrench_aos): positions (n,3), orientations
+// (n,4) wxyz or xyzw, velocities (n,6) in; forces (n,3), torques (n,3) out; previous velocity and parameters are the
+// engine's tiled records.  168 B per body-step, all of it real traffic.
+//
+// Every lane reads ITS body's rows straight into registers - 12 B of position (global_load_dwordx3), 16 B of
+// orientation (dwordx4), 24 B of velocity (dwordx4 + dwordx2) - and writes its force and torque rows as dwordx3.  A
+// wave-instruction covers one contiguous 768-B / 1 024-B / 1 536-B run, so whole lines are consumed and the
+// transposition costs nothing: gfx950 takes 4-byte-aligned wide accesses (unaligned access mode is on under HSA).
+// Measured against the LDS-staged form below (whole 16-byte chunks per wave into a wave-private LDS slice, rows picked
+// up with conflict-free strides, three wavefront fences): 30.3 vs 34.0 us at 1 M bodies, 111.6 vs 113.7 us at 4 M,
+// identical bits; 91 % / 100 % of a memory-only probe of the same traffic (scripts/probes.py).
+// --------------------------------------------------------------------------
+typedef float f3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef float f4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+// (one function per type: a template parameter would drop the typedef's alignment and let the compiler assume 16)
+#define HYDRO_WIDE_ACCESS(T)                                                                                              \
+    template <bool NT> __device__ __forceinline__ T ld_##T(const void* base, uint32_t byte_off)                              \
+    { const T* q = reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off); if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; } \
+    template <bool NT> __device__ __forceinline__ void st_##T(void* base, uint32_t byte_off, T v)                            \
+    { T* q = reinterpret_cast<T*>(static_cast<char*>(base) + byte_off); if constexpr (NT) __builtin_nontemporal_store(v, q); else *q = v; }
+HYDRO_WIDE_ACCESS(f3_a4)
+HYDRO_WIDE_ACCESS(f4_a8)
+HYDRO_WIDE_ACCESS(f2_a8)
+HYDRO_WIDE_ACCESS(f4_a16)
+#undef HYDRO_WIDE_ACCESS
+
+template <bool HALF, bool NT>
+__global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* k_pos, const float* k_quat, const float* k_vel, float* k_force, float* k_torque,
+                                                                  float* k_pv, const float* k_prm, int quat_xyzw, uint32_t n,      // 16 dwords: preloaded
+                                                                  int warp, double rho, double g, double inv_dt)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
+    const f3_a4 p = ld_f3_a4<NT>(k_pos, i * 12u);
+    const f4_a16 q = ld_f4_a16<NT>(k_quat, i * 16u);
+    const f4_a8 v0 = ld_f4_a8<NT>(k_vel, i * 24u);
+    const f2_a8 v1 = ld_f2_a8<NT>(k_vel, i * 24u + 16u);
+    s[0] = p.x; s[1] = p.y; s[2] = p.z;
+    if (quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
+    else           { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
+    s[7] = v0.x; s[8] = v0.y; s[9] = v0.z; s[10] = v0.w; s[11] = v1.x; s[12] = v1.y;
+    const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + lane) * 4u;
+#pragma unroll
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(k_pv, po, f * 256u));
+    if constexpr (HALF) {
+        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(k_prm, qo, f * 256u));
+        mass = ldg<NT>(at<float>(k_prm, qo, 3 * 256u));
+        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(k_prm, ho, f * 128u)));
+    } else {
+        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(k_prm, qo, f * 256u));
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(k_prm, qo + (3 + f) * 256u));
+        mass = ldg<NT>(at<float>(k_prm, qo, 10 * 256u));
+    }
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, warp != 0);
+#pragma unroll
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(k_pv, po, f * 256u), s[7 + f]);
+    f3_a4 fo, to;
+    fo.x = w.fx; fo.y = w.fy; fo.z = w.fz; to.x = w.tx; to.y = w.ty; to.z = w.tz;
+    st_f3_a4<NT>(k_force, i * 12u, fo);
+    st_f3_a4<NT>(k_torque, i * 12u, to);
+}
+
+#if HYDRO_AB_AOS_LDS
+// A/B arm (not compiled into the product): the same entry with the transposition staged through LDS.
+// One block = 256 consecutive bodies.  positions (256x3) and velocities (256x6) are read
+// as whole 16-B chunks (fully coalesced), parked in a wave-private LDS slice and picked up per body with
+// conflict-free strides (3 and 6 dwords: odd / 2*odd); orientations are one float4 per
+// lane already.  Forces and torques take the same road back.
 template <bool HALF, bool NT>
 __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const float* k_pos, const float* k_quat, const float* k_vel, float* k_force, float* k_torque,
                                                            float* k_pv, const float* k_prm, int quat_xyzw, uint32_t n32,      // 16 dwords: preloaded
@@ -550,6 +805,7 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const float* k_pos, 
         }
     }
 }
+#endif  // HYDRO_AB_AOS_LDS
 
 // --------------------------------------------------------------------------
 // component mode (compatibility / debug surface, not a benchmark mode)
@@ -644,74 +900,57 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
 }
 
 // --------------------------------------------------------------------------
-// kinetic energy: wave64 shuffle -> LDS across the 4 waves -> one fp64 partial pair per
-// block -> fixed-order second stage (deterministic, no atomics).
+// kinetic energy: per body in fp64 (hydro_body.h), wave64 shuffle -> LDS across the block's 4 waves -> ONE fp64
+// pair per block of 256 consecutive bodies -> fixed-order second stage.  Deterministic, no atomics; the
+// decomposition (which bodies make which partial, in which order everything is added) is the same whether the
+// first stage runs stand-alone (ke_partial_kernel) or inside a wrench / step kernel that has the bodies in
+// registers anyway (KE template argument there): both give the same bits.
 // --------------------------------------------------------------------------
+// Stand-alone first stage: one body per lane, every load issued before the first use.  State from plain SoA field
+// pointers or from a tiled buffer (one address rule, see IntArgs); dimensions and mass from the engine's tiled
+// parameter record.  56 B read per body with the rotational term (40 of the 52 state bytes + 16), 16 + 4 without.
 struct KeArgs {
-    const float* st[HYDRO_STATE_FIELDS];   // plain SoA field pointers, or tiled base + f*64 (see IntArgs)
+    const float* st[HYDRO_STATE_FIELDS];   // plain SoA field pointers, or tiled base + f*64
     uint32_t st_stride, shift, mask;
-    const float* dims[3];
-    const float* mass;
-    double* partials;      // [2 * kKeBlocks]
-    double* out;           // [2]
+    const float* prm;                      // engine-owned tiled parameter record
+    uint32_t prm_tile_floats, mass_field;  // 704 / 10 (fp32 record) or 480 / 3 (fp16-coefficient record)
+    double* partials; uint32_t partial_stride;
     int rotational;
-    int64_t n;
+    uint32_t n;
 };
-
-__device__ __forceinline__ double wave_sum(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
-}
 
 __global__ void __launch_bounds__(kBlock) ke_partial_kernel(const KeArgs a)
 {
-    __shared__ double red[2][kBlock / 64];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     double lin = 0.0, rot = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
-        const uint32_t o = ((uint32_t)i >> a.shift) * a.st_stride + ((uint32_t)i & a.mask);
-        const float m = a.mass[i];
-        const float vx = a.st[7][o], vy = a.st[8][o], vz = a.st[9][o];
-        lin += 0.5 * (double)m * ((double)vx * vx + (double)vy * vy + (double)vz * vz);
+    if (i < a.n) {
+        const uint32_t o = (i >> a.shift) * a.st_stride + (i & a.mask);
+        const float* q = a.prm + (size_t)(i >> 6) * a.prm_tile_floats + (i & 63u);
+        const float m = __builtin_nontemporal_load(q + a.mass_field * 64u);
+        const float vx = __builtin_nontemporal_load(a.st[7] + o), vy = __builtin_nontemporal_load(a.st[8] + o), vz = __builtin_nontemporal_load(a.st[9] + o);
+        float qx = 0.f, qy = 0.f, qz = 0.f, qw = 1.f, wx = 0.f, wy = 0.f, wz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
         if (a.rotational) {
-            const float qx = a.st[3][o], qy = a.st[4][o], qz = a.st[5][o], qw = a.st[6][o];
-            const float wx = a.st[10][o], wy = a.st[11][o], wz = a.st[12][o];
-            const float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
-            const float xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
-            const float sx = qw * x2, sy = qw * y2, sz = qw * z2;
-            // w_b = R^T w
-            const float bx = (1.0f - (yy + zz)) * wx + (xy + sz) * wy + (xz - sy) * wz;
-            const float by = (xy - sz) * wx + (1.0f - (xx + zz)) * wy + (yz + sx) * wz;
-            const float bz = (xz + sy) * wx + (yz - sx) * wy + (1.0f - (xx + yy)) * wz;
-            const float dx = a.dims[0][i], dy = a.dims[1][i], dz = a.dims[2][i];
-            const double k = (double)m / 12.0;
-            rot += 0.5 * k * ((double)(dy * dy + dz * dz) * bx * bx + (double)(dx * dx + dz * dz) * by * by
-                              + (double)(dx * dx + dy * dy) * bz * bz);
+            qx = __builtin_nontemporal_load(a.st[3] + o); qy = __builtin_nontemporal_load(a.st[4] + o);
+            qz = __builtin_nontemporal_load(a.st[5] + o); qw = __builtin_nontemporal_load(a.st[6] + o);
+            wx = __builtin_nontemporal_load(a.st[10] + o); wy = __builtin_nontemporal_load(a.st[11] + o); wz = __builtin_nontemporal_load(a.st[12] + o);
+            dx = __builtin_nontemporal_load(q); dy = __builtin_nontemporal_load(q + 64); dz = __builtin_nontemporal_load(q + 128);
         }
+        hydro::kinetic_energy(qx, qy, qz, qw, vx, vy, vz, wx, wy, wz, dx, dy, dz, m, a.rotational != 0, lin, rot);
     }
-    lin = wave_sum(lin);
-    rot = wave_sum(rot);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = lin; red[1][wave] = rot; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double l = 0.0, r = 0.0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) { l += red[0][w]; r += red[1][w]; }
-        a.partials[blockIdx.x] = l;
-        a.partials[kKeBlocks + blockIdx.x] = r;
-    }
+    ke_block_partial(lin, rot, a.partials, a.partial_stride);
 }
 
-__global__ void __launch_bounds__(kBlock) ke_final_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+// Second stage: ONE block adds the per-block partials in a fixed order (thread t takes t, t + 1024, ...; then a tree).
+__global__ void __launch_bounds__(kKeFinalBlock) ke_final_kernel(const double* __restrict__ partials, uint32_t nblocks, uint32_t stride,
+                                                                 double* __restrict__ out)
 {
-    __shared__ double red[2][kBlock];
+    __shared__ double red[2][kKeFinalBlock];
     double l = 0.0, r = 0.0;
-    for (int k = threadIdx.x; k < nblocks; k += kBlock) { l += partials[k]; r += partials[kKeBlocks + k]; }
+#pragma unroll 8
+    for (uint32_t k = threadIdx.x; k < nblocks; k += kKeFinalBlock) { l += partials[k]; r += partials[stride + k]; }
     red[0][threadIdx.x] = l; red[1][threadIdx.x] = r;
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
+    for (int s = kKeFinalBlock / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
         __syncthreads();
     }
@@ -727,8 +966,8 @@ struct IntArgs {
     const float* si[HYDRO_STATE_FIELDS]; uint32_t si_stride;
     const float* w[HYDRO_WRENCH_FIELDS]; uint32_t w_stride;
     float* so[HYDRO_STATE_FIELDS];       uint32_t so_stride;
-    const float* dims[3];                // always the engine's plain-SoA copy
-    const float* mass;
+    const float* prm;                    // engine-owned tiled parameter record (dimensions, mass)
+    uint32_t prm_tile_floats, mass_field;  // 704 / 10 (fp32 record) or 480 / 3 (fp16-coefficient record)
     uint32_t shift, mask;
     float g, dt;
     uint32_t n;
@@ -811,7 +1050,8 @@ __global__ void __launch_bounds__(kBlock) integrate_kernel(const IntArgs a)
     for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) s[k] = a.si[k][oi];
 #pragma unroll
     for (int k = 0; k < HYDRO_WRENCH_FIELDS; ++k) f[k] = a.w[k][ow];
-    integrate_body<false>(s, f, a.mass[i], a.dims[0][i], a.dims[1][i], a.dims[2][i], a.g, a.dt, 0.0f, 0.0f, o);
+    const float* q = a.prm + (size_t)(i >> 6) * a.prm_tile_floats + (i & 63u);
+    integrate_body<false>(s, f, q[a.mass_field * 64u], q[0], q[64], q[128], a.g, a.dt, 0.0f, 0.0f, o);
 #pragma unroll
     for (int k = 0; k < HYDRO_STATE_FIELDS; ++k) a.so[k][oo] = o[k];
 }
@@ -828,10 +1068,12 @@ struct FusedArgs {
     float dt;
 };
 
-template <bool HALF, bool NT, bool IMPLICIT>
+// KE = true: also samples the kinetic energy of the state it WRITES (the state after this step), see wrench_tiled_kernel.
+template <bool HALF, bool NT, bool IMPLICIT, bool KE = false>
 __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_so, float* k_out,
                                                                  uint32_t st_stride, uint32_t pv_stride, uint32_t so_stride, uint32_t out_stride,
-                                                                 uint32_t n, int warp, float dt, double rho, double g, double inv_dt)
+                                                                 uint32_t n, int warp, float dt, double rho, double g, double inv_dt,
+                                                                 double* ke_partials, uint32_t ke_stride, int ke_rotational)
 {
     FusedArgs fa;                               // (scalar arguments: see wrench_tiled_kernel)
     fa.t.st = k_st; fa.t.st_stride = st_stride; fa.t.pv = k_pv; fa.t.pv_stride = pv_stride; fa.t.pv_out = nullptr; fa.t.pvo_stride = 0;
@@ -839,31 +1081,34 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k
     fa.so = k_so; fa.so_stride = so_stride; fa.dt = dt;
     const TiledArgs& a = fa.t;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t tile = i >> 6, lane = i & 63u;
-    const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
-    const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
-    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-    load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
-    const float k_lin = w.k_lin, k_ang = w.k_ang;     // used by the implicit form only
-    const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
-    float o[HYDRO_STATE_FIELDS];
-    integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, k_lin, k_ang, o);
-    const uint32_t oo = (__umul24(tile, fa.so_stride) + lane) * 4u;
-#pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(fa.so, oo, f * 256u), o[f]);
-    if (a.out) {
-        const uint32_t wo = (__umul24(tile, a.out_stride) + lane) * 4u;
-#pragma unroll
-        for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(a.out, wo, f * 256u), f6[f]);
+    if constexpr (!KE) {
+        if (i >= a.n) return;
     }
-}
-
-__global__ void __launch_bounds__(kBlock) to_half_kernel(const float* __restrict__ src, __half* __restrict__ dst, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) dst[i] = __float2half_rn(src[i]);
+    double ke_lin = 0.0, ke_rot = 0.0;
+    if (!KE || i < a.n) {
+        const uint32_t tile = i >> 6, lane = i & 63u;
+        const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
+        const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
+        float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
+        load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+        const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+        const float k_lin = w.k_lin, k_ang = w.k_ang;     // used by the implicit form only
+        const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
+        float o[HYDRO_STATE_FIELDS];
+        integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], a.g, fa.dt, k_lin, k_ang, o);
+        if constexpr (KE)
+            hydro::kinetic_energy(o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], d[0], d[1], d[2], mass,
+                                  ke_rotational != 0, ke_lin, ke_rot);
+        const uint32_t oo = (__umul24(tile, fa.so_stride) + lane) * 4u;
+#pragma unroll
+        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(fa.so, oo, f * 256u), o[f]);
+        if (a.out) {
+            const uint32_t wo = (__umul24(tile, a.out_stride) + lane) * 4u;
+#pragma unroll
+            for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(a.out, wo, f * 256u), f6[f]);
+        }
+    }
+    if constexpr (KE) ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
 }
 
 }  // namespace
@@ -879,19 +1124,26 @@ struct hydro_engine {
     double rho = 1025.0, g = 9.81;
     int semantics = HYDRO_SEM_NUMBA;
     bool half_coeffs = false;
-    float* params = nullptr;       // [11][stride] fp32
-    __half* coeffs16 = nullptr;    // [7][stride]
-    float* prev = nullptr;         // [6][stride]
+    // What the engine holds for every body: the tiled parameter record (44 B) and the tiled previous velocity (24 B).
     float* params_tiled = nullptr; // [tiles][11][64] f32 or [tiles][480] (fp16-coefficient record)
     float* prev_tiled = nullptr;   // [tiles][6][64]
-    double* ke_partials = nullptr; // [2 * kKeBlocks]
+    // Plain-SoA copies, made on the FIRST use of an entry point that takes plain field pointers (hydro_step_wrench,
+    // _ext, hydro_step_components) and kept up to date from then on: a caller of the tiled / array-of-structs /
+    // fused entries never pays their 82 B per body.
+    float* params = nullptr;       // [11][stride] fp32
+    __half* coeffs16 = nullptr;    // [7][stride]   (fp16-coefficient mode)
+    float* prev = nullptr;         // [6][stride]
+    bool soa_params_valid = false; // `params` / `coeffs16` reflect params_tiled
+    double* ke_partials = nullptr; // [2][ke_stride]: one fp64 pair per block of 256 bodies
+    uint32_t ke_stride = 0;
     hipStream_t stream = nullptr;
     int vec = 0;                   // bodies per lane, 0 = default (1)
     int block = 0;                 // threads per block, 0 = by size
     int nt = -1;                   // non-temporal accesses: -1 = by size, 0 = off, 1 = on
     int waves = -1;                // resident waves per SIMD of the tiled wrench kernel: -1 = by size, 0 = no cap
-    // the engine-owned previous velocity exists in both layouts; which copy is current:
-    enum PrevCopy { kPrevBoth, kPrevSoa, kPrevTiled } prev_current = kPrevBoth;
+    // the engine-owned previous velocity may exist in both layouts; which copy is current (a plain-SoA copy that has
+    // not been allocated yet counts as stale):
+    enum PrevCopy { kPrevBoth, kPrevSoa, kPrevTiled } prev_current = kPrevTiled;
     char err[512] = {0};
 };
 
@@ -940,6 +1192,42 @@ void fill_params(hydro_engine* h, Args& a)
     for (int f = 0; f < 7; ++f)
         a.coef[f] = h->half_coeffs ? static_cast<const void*>(h->coeffs16 + f * h->stride)
                                    : static_cast<const void*>(h->params + (3 + f) * h->stride);
+}
+
+// tiled parameter record: floats per tile and the field that holds the mass
+inline uint32_t prm_tile_floats(const hydro_engine* h) { return h->half_coeffs ? kPrmTileF16 : kPrmTileF32; }
+inline uint32_t prm_mass_field(const hydro_engine* h) { return h->half_coeffs ? 3u : 10u; }
+
+// The plain-SoA copies of the parameters, made from the tiled record on the first use of a plain-SoA entry point
+// (and after every hydro_set_params_* from then on).  Allocates: not capturable on that first use - call the entry
+// once, or hydro_reserve_soa, before capturing a graph.
+int ensure_soa_params(hydro_engine* h, hipStream_t s)
+{
+    const size_t fbytes = sizeof(float) * (size_t)h->stride;
+    if (!h->params && hipMalloc(&h->params, fbytes * HYDRO_PARAM_FIELDS) != hipSuccess)
+        return fail(h, HYDRO_E_ALLOC, "plain-SoA parameter copy: allocation failed (first use of a plain-SoA entry point allocates; not inside a graph capture)");
+    if (h->half_coeffs && !h->coeffs16 && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) != hipSuccess)
+        return fail(h, HYDRO_E_ALLOC, "plain-SoA fp16 coefficient copy: allocation failed");
+    if (!h->soa_params_valid && h->n_params > 0) {
+        hipLaunchKernelGGL(params_from_tiled_kernel, dim3(grid_for(h->n_params, kBlock)), dim3(kBlock), 0, s,
+                           h->params_tiled, h->half_coeffs ? 1 : 0, h->params, h->stride, h->coeffs16, (uint32_t)h->n_params);
+        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+        HYDRO_HIP(h, hipStreamSynchronize(s), HYDRO_E_LAUNCH);      // once: later calls may come on other streams
+    }
+    h->soa_params_valid = true;
+    return HYDRO_OK;
+}
+
+int ensure_soa_prev(hydro_engine* h)
+{
+    if (h->prev) return HYDRO_OK;
+    const size_t bytes = sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS;
+    if (hipMalloc(&h->prev, bytes) != hipSuccess)
+        return fail(h, HYDRO_E_ALLOC, "plain-SoA previous-velocity copy: allocation failed (first use of hydro_step_wrench allocates; not inside a graph capture)");
+    HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, bytes, h->stream), HYDRO_E_LAUNCH);
+    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    if (h->prev_current == hydro_engine::kPrevBoth) h->prev_current = hydro_engine::kPrevTiled;   // the new copy is stale
+    return HYDRO_OK;
 }
 
 // Launch geometry, measured on MI355X (scripts/tune.py, interleaved A/B):
@@ -1035,26 +1323,28 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
         a.out[f] = wrench[f];
         while (vec > 1 && !aligned_to(wrench[f], sizeof(float) * vec)) vec >>= 1;
     }
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = ensure_soa_params(h, s))) return rc;                 // plain-SoA parameter copies: made on first use
     fill_params(h, a);
     a.mass = h->params + 10 * h->stride;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics;
     a.inv_dt = 1.0 / dt;
     a.n = n;
-    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec >= 2) launch_soa<2, WRITE_PREV>(h, a, s);
     else launch_soa<1, WRITE_PREV>(h, a, s);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
 
-int copy_fields(hydro_engine* h, float* dst, int64_t dst_stride, const float* const src[], int nfields, int64_t n, int on_device)
+// A temporary device copy of `nfields` host arrays of n floats ([nfields][n]); the caller frees it.
+int stage_host_fields(hydro_engine* h, const float* const src[], int nfields, int64_t n, float** staged)
 {
+    *staged = nullptr;
+    if (hipMalloc(staged, sizeof(float) * (size_t)n * nfields) != hipSuccess) return fail(h, HYDRO_E_ALLOC, "staging buffer: allocation failed");
     for (int f = 0; f < nfields; ++f) {
-        if (!src[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
-        HYDRO_HIP(h, hipMemcpyAsync(dst + f * dst_stride, src[f], sizeof(float) * n,
-                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream),
-                  HYDRO_E_LAUNCH);
+        hipError_t e = hipMemcpyAsync(*staged + (size_t)f * n, src[f], sizeof(float) * n, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { (void)hipFree(*staged); *staged = nullptr; return fail(h, HYDRO_E_LAUNCH, "hipMemcpyAsync (host -> device)", e); }
     }
     return HYDRO_OK;
 }
@@ -1064,25 +1354,31 @@ int set_params(hydro_engine* h, int64_t n, const float* const params[], int on_d
     if (!h) return HYDRO_E_ARG;
     if (!params) return fail(h, HYDRO_E_ARG, "null pointer table");
     if (n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "n out of range (0 <= n <= capacity)");
+    for (int f = 0; f < HYDRO_PARAM_FIELDS; ++f) if (!params[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    int rc = copy_fields(h, h->params, h->stride, params, HYDRO_PARAM_FIELDS, n, on_device);
-    if (rc) return rc;
-    if (half && n > 0) {
-        for (int f = 0; f < 7; ++f)
-            hipLaunchKernelGGL(to_half_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, h->stream,
-                               h->params + (3 + f) * h->stride, h->coeffs16 + f * h->stride, n);
-        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    }
     if (n > 0) {
+        // straight from the caller's arrays into the tiled records (host arrays go through a temporary device copy)
+        ParamPtrs src;
+        float* staged = nullptr;
+        if (on_device) {
+            for (int f = 0; f < HYDRO_PARAM_FIELDS; ++f) src.f[f] = params[f];
+        } else {
+            int rc = stage_host_fields(h, params, HYDRO_PARAM_FIELDS, n, &staged);
+            if (rc) return rc;
+            for (int f = 0; f < HYDRO_PARAM_FIELDS; ++f) src.f[f] = staged + (size_t)f * n;
+        }
         const uint32_t n_pad = (uint32_t)((n + 63) / 64 * 64);
         hipLaunchKernelGGL(params_to_tiled_kernel, dim3(grid_for(n_pad, kBlock)), dim3(kBlock), 0, h->stream,
-                           h->params, h->stride, h->coeffs16, h->params_tiled, half ? 1 : 0, n_pad, (uint32_t)n);
-        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+                           src, h->params_tiled, half ? 1 : 0, n_pad, (uint32_t)n);
+        hipError_t e = hipGetLastError();
+        // the source arrays may be pageable host memory, or device memory that the caller frees right away
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (staged) (void)hipFree(staged);
+        if (e != hipSuccess) return fail(h, HYDRO_E_LAUNCH, "params_to_tiled_kernel", e);
     }
-    // the source arrays may be pageable host memory that the caller frees right away
-    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
     h->half_coeffs = half;
     h->n_params = n;
+    h->soa_params_valid = false;                 // the plain-SoA copies (if any entry point ever asked for them) are refreshed on next use
     return HYDRO_OK;
 }
 
@@ -1109,11 +1405,24 @@ int check_tiled(hydro_engine* h, int64_t n, const void* p, int64_t stride, int f
     return HYDRO_OK;
 }
 
+// second stage of the kinetic-energy reduction for the first `n` bodies' per-block partials
+int ke_finish(hydro_engine* h, int64_t n, double* out_dev, hipStream_t s)
+{
+    const uint32_t blocks = (uint32_t)grid_for(n > 0 ? n : 1, kBlock);
+    hipLaunchKernelGGL(ke_final_kernel, dim3(1), dim3(kKeFinalBlock), 0, s, h->ke_partials, n > 0 ? blocks : 0u, h->ke_stride, out_dev);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
+}
+
 // Bring the copy of the engine-owned previous velocity that `want` names up to date (a repack
 // kernel on the caller's stream when the other layout was written last), then mark it as the one
-// that is about to be written.
+// that is about to be written.  The plain-SoA copy is allocated on its first use.
 int prev_acquire(hydro_engine* h, hydro_engine::PrevCopy want, int64_t n, hipStream_t s)
 {
+    if (want == hydro_engine::kPrevSoa) {
+        int rc = ensure_soa_prev(h);
+        if (rc) return rc;
+    }
     if (h->prev_current != hydro_engine::kPrevBoth && h->prev_current != want && n > 0) {
         float* rows[HYDRO_PREV_FIELDS];
         for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
@@ -1165,17 +1474,16 @@ int hydro_create(int device, int64_t capacity, hydro_t** out)
     if (!h) return HYDRO_E_ALLOC;
     h->device = device;
     h->capacity = capacity;
-    h->stride = (capacity + 1023) / 1024 * 1024;          // 4 KiB-aligned fields
+    h->stride = (capacity + 1023) / 1024 * 1024;          // 4 KiB-aligned fields; a whole number of tiles
+    h->ke_stride = (uint32_t)((capacity + kBlock - 1) / kBlock);
     const size_t fbytes = sizeof(float) * (size_t)h->stride;
+    // 68 B per body: tiled parameters + tiled previous velocity (+ 1/16 B of reduction scratch).  The plain-SoA
+    // copies (82 B per body more) come with the first call of an entry point that needs them.
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipMalloc(&h->params, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
-    ok = ok && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) == hipSuccess;
-    ok = ok && hipMalloc(&h->prev, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
     ok = ok && hipMalloc(&h->params_tiled, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
     ok = ok && hipMalloc(&h->prev_tiled, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
     ok = ok && hipMemsetAsync(h->prev_tiled, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
-    ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * 2 * kKeBlocks) == hipSuccess;
-    ok = ok && hipMemsetAsync(h->prev, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
+    ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * 2 * (size_t)h->ke_stride) == hipSuccess;
     ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
     if (!ok) { hydro_destroy(h); return HYDRO_E_ALLOC; }
     *out = h;
@@ -1194,6 +1502,23 @@ int hydro_destroy(hydro_t* h)
     if (h->prev_tiled) (void)hipFree(h->prev_tiled);
     if (h->ke_partials) (void)hipFree(h->ke_partials);
     delete h;
+    return HYDRO_OK;
+}
+
+int hydro_reserve_soa(hydro_t* h)
+{
+    if (!h) return HYDRO_E_ARG;
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    int rc = ensure_soa_params(h, h->stream);
+    if (rc) return rc;
+    if ((rc = ensure_soa_prev(h))) return rc;
+    if (h->prev_current == hydro_engine::kPrevTiled && h->n_params > 0) {      // bring the plain copy up to date
+        float* rows[HYDRO_PREV_FIELDS];
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
+        if ((rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, h->n_params, false, h->stream))) return rc;
+        HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+        h->prev_current = hydro_engine::kPrevBoth;
+    }
     return HYDRO_OK;
 }
 
@@ -1224,10 +1549,10 @@ int hydro_reset_prev_velocity(hydro_t* h)
 {
     if (!h) return HYDRO_E_ARG;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
+    if (h->prev) HYDRO_HIP(h, hipMemsetAsync(h->prev, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipMemsetAsync(h->prev_tiled, 0, sizeof(float) * (size_t)h->stride * HYDRO_PREV_FIELDS, h->stream), HYDRO_E_LAUNCH);
     HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
-    h->prev_current = hydro_engine::kPrevBoth;
+    h->prev_current = h->prev ? hydro_engine::kPrevBoth : hydro_engine::kPrevTiled;
     return HYDRO_OK;
 }
 
@@ -1235,20 +1560,34 @@ int hydro_get_prev_velocity(hydro_t* h, int64_t n, float* const prev[HYDRO_PREV_
 {
     if (!h) return HYDRO_E_ARG;
     if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) if (!prev[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
+    if (n == 0) return HYDRO_OK;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    if (h->prev_current == hydro_engine::kPrevTiled && n > 0) {   // last written in tiled form: refresh the SoA copy
-        float* rows[HYDRO_PREV_FIELDS];
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
-        int rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, false, h->stream);
-        if (rc) return rc;
-        h->prev_current = hydro_engine::kPrevBoth;
+    if (h->prev_current == hydro_engine::kPrevSoa) {              // last written by a plain-SoA step: that copy is the current one
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f)
+            HYDRO_HIP(h, hipMemcpyAsync(prev[f], h->prev + f * h->stride, sizeof(float) * n,
+                                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream), HYDRO_E_LAUNCH);
+        HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+        return HYDRO_OK;
     }
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) {
-        if (!prev[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
-        HYDRO_HIP(h, hipMemcpyAsync(prev[f], h->prev + f * h->stride, sizeof(float) * n,
-                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream), HYDRO_E_LAUNCH);
+    // from the tiled records: straight into device arrays, through a temporary device copy into host arrays
+    float* rows[HYDRO_PREV_FIELDS];
+    float* staged = nullptr;
+    if (on_device) {
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = prev[f];
+    } else {
+        if (hipMalloc(&staged, sizeof(float) * (size_t)n * HYDRO_PREV_FIELDS) != hipSuccess) return fail(h, HYDRO_E_ALLOC, "staging buffer: allocation failed");
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = staged + (size_t)f * n;
     }
-    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    int rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, false, h->stream);
+    hipError_t e = hipSuccess;
+    if (!rc && staged)
+        for (int f = 0; f < HYDRO_PREV_FIELDS && e == hipSuccess; ++f)
+            e = hipMemcpyAsync(prev[f], rows[f], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (staged) (void)hipFree(staged);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(h, HYDRO_E_LAUNCH, "hydro_get_prev_velocity", e);
     return HYDRO_OK;
 }
 
@@ -1256,16 +1595,27 @@ int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO
 {
     if (!h) return HYDRO_E_ARG;
     if (!prev || n < 0 || n > h->capacity) return fail(h, HYDRO_E_ARG, "bad arguments");
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) if (!prev[f]) return fail(h, HYDRO_E_ARG, "null field pointer");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    int rc = copy_fields(h, h->prev, h->stride, prev, HYDRO_PREV_FIELDS, n, on_device);
-    if (rc) return rc;
     if (n > 0) {
+        // if a plain-SoA step ran last, the bodies beyond n keep what it left: bring the tiled records up to date first
+        int rc = prev_acquire(h, hydro_engine::kPrevTiled, h->n_params, h->stream);
+        if (rc) return rc;
         float* rows[HYDRO_PREV_FIELDS];
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = h->prev + f * h->stride;
-        if ((rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, true, h->stream))) return rc;
+        float* staged = nullptr;
+        if (on_device) {
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = const_cast<float*>(prev[f]);     // read only (to_tiled)
+        } else {
+            if ((rc = stage_host_fields(h, prev, HYDRO_PREV_FIELDS, n, &staged))) return rc;
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) rows[f] = staged + (size_t)f * n;
+        }
+        rc = repack(h, rows, HYDRO_PREV_FIELDS, h->prev_tiled, HYDRO_PREV_FIELDS * HYDRO_TILE, n, true, h->stream);
+        const hipError_t e = hipStreamSynchronize(h->stream);
+        if (staged) (void)hipFree(staged);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(h, HYDRO_E_LAUNCH, "hydro_set_prev_velocity", e);
     }
-    h->prev_current = hydro_engine::kPrevBoth;
-    HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);
+    h->prev_current = hydro_engine::kPrevTiled;          // a plain-SoA copy, if there is one, is refreshed on its next use
     return HYDRO_OK;
 }
 
@@ -1273,11 +1623,11 @@ int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STAT
                       float* const wrench[HYDRO_WRENCH_FIELDS], void* stream)
 {
     if (!h) return HYDRO_E_ARG;
-    float* pv[HYDRO_PREV_FIELDS];
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = h->prev + f * h->stride;
-    if (n > 0 && n <= h->capacity && hipSetDevice(h->device) == hipSuccess) {
-        int rc = prev_acquire(h, hydro_engine::kPrevSoa, n, static_cast<hipStream_t>(stream));
+    float* pv[HYDRO_PREV_FIELDS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (n > 0 && n <= h->capacity && use_device(h->device) == hipSuccess) {
+        int rc = prev_acquire(h, hydro_engine::kPrevSoa, n, static_cast<hipStream_t>(stream));   // (allocates the plain copy on first use)
         if (rc) return rc;
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = h->prev + f * h->stride;
     }
     return step_soa<true>(h, n, state, pv, pv, dt, wrench, stream);
 }
@@ -1290,9 +1640,13 @@ int hydro_step_wrench_ext(hydro_t* h, int64_t n, const float* const state[HYDRO_
     return step_soa<false>(h, n, state, prev, nullptr, dt, wrench, stream);
 }
 
-int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
-                            const float* prev, int64_t prev_tile_stride, double dt,
-                            float* wrench, int64_t wrench_tile_stride, void* stream)
+}  // extern "C"
+
+namespace {
+// hydro_step_wrench_tiled, optionally sampling the kinetic energy of the state it reads (ke_out != nullptr)
+int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                           const float* prev, int64_t prev_tile_stride, double dt,
+                           float* wrench, int64_t wrench_tile_stride, int ke_rotational, double* ke_out, void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
@@ -1301,7 +1655,8 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
     if ((rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench"))) return rc;
     const bool own_prev = (prev == nullptr);
     if (!own_prev && (rc = check_tiled(h, n, prev, prev_tile_stride, HYDRO_PREV_FIELDS, "null prev"))) return rc;
-    if (n == 0) return HYDRO_OK;
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    if (n == 0) return ke_out ? ke_finish(h, 0, ke_out, static_cast<hipStream_t>(stream)) : HYDRO_OK;
     TiledArgs a;
     a.st = state; a.st_stride = (uint32_t)state_tile_stride;
     if (own_prev) { a.pv = h->prev_tiled; a.pv_stride = HYDRO_PREV_FIELDS * HYDRO_TILE; a.pv_out = h->prev_tiled; a.pvo_stride = a.pv_stride; }
@@ -1309,11 +1664,10 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
     a.prm = h->params_tiled;
     a.out = wrench; a.out_stride = (uint32_t)wrench_tile_stride;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = (uint32_t)n;
-    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (own_prev && (rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
-    const int block = h->block ? h->block : 256;
+    const int block = (h->block && !ke_out) ? h->block : 256;               // (the energy partials are one per 256 bodies)
     const dim3 grid(grid_for(n, block)), blk(block);
     // Occupancy shaping: the kernel uses no LDS, so a dynamic-LDS request is a pure residency cap
     // (160 KB per CU / blocks per CU).  Fewer resident waves = fewer DRAM streams in flight.
@@ -1324,18 +1678,60 @@ int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t s
         lds = blocks_per_cu > 0 ? ((size_t)160 * 1024 / (size_t)blocks_per_cu) & ~(size_t)255 : 0;
         if (lds > 64 * 1024) lds = 64 * 1024;                               // per-block LDS limit
     }
-#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, lds, s, \
-        a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt)
+#define HYDRO_TILED_ARGS a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt, \
+        h->ke_partials, h->ke_stride, ke_rotational
+#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, lds, s, HYDRO_TILED_ARGS)
 #define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
 #define HYDRO_TILED_WP(BLOCK, HALF) do { if (own_prev) HYDRO_TILED_NT(BLOCK, HALF, true); else HYDRO_TILED_NT(BLOCK, HALF, false); } while (0)
 #define HYDRO_TILED_HALF(BLOCK) do { if (h->half_coeffs) HYDRO_TILED_WP(BLOCK, true); else HYDRO_TILED_WP(BLOCK, false); } while (0)
-    if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
+#if HYDRO_AB_TILED_LDS
+    {
+        const dim3 g256(grid_for(n, kBlock)), b256(kBlock);
+#define HYDRO_LDS_LAUNCH(HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_lds_kernel<HALF, WP, NT>), g256, b256, 0, s, \
+        a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt)
+#define HYDRO_LDS_NT(HALF, WP) do { if (nt) HYDRO_LDS_LAUNCH(HALF, WP, true); else HYDRO_LDS_LAUNCH(HALF, WP, false); } while (0)
+#define HYDRO_LDS_WP(HALF) do { if (own_prev) HYDRO_LDS_NT(HALF, true); else HYDRO_LDS_NT(HALF, false); } while (0)
+        if (h->half_coeffs) HYDRO_LDS_WP(true); else HYDRO_LDS_WP(false);
+#undef HYDRO_LDS_WP
+#undef HYDRO_LDS_NT
+#undef HYDRO_LDS_LAUNCH
+    }
+#else
+    if (ke_out) {
+        // the sampling variant: same body, same bits, plus one fp64 pair per block; then the fixed-order second stage
+#define HYDRO_TILED_KE(HALF, WP) do { if (nt) hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, true, true>), grid, blk, lds, s, HYDRO_TILED_ARGS); \
+                                      else hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, false, true>), grid, blk, lds, s, HYDRO_TILED_ARGS); } while (0)
+        if (h->half_coeffs) { if (own_prev) HYDRO_TILED_KE(true, true); else HYDRO_TILED_KE(true, false); }
+        else { if (own_prev) HYDRO_TILED_KE(false, true); else HYDRO_TILED_KE(false, false); }
+#undef HYDRO_TILED_KE
+    } else if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
+#endif
 #undef HYDRO_TILED_HALF
 #undef HYDRO_TILED_WP
 #undef HYDRO_TILED_NT
 #undef HYDRO_TILED_LAUNCH
+#undef HYDRO_TILED_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    return HYDRO_OK;
+    return ke_out ? ke_finish(h, n, ke_out, s) : HYDRO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hydro_step_wrench_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                            const float* prev, int64_t prev_tile_stride, double dt,
+                            float* wrench, int64_t wrench_tile_stride, void* stream)
+{
+    return step_wrench_tiled_impl(h, n, state, state_tile_stride, prev, prev_tile_stride, dt, wrench, wrench_tile_stride, 0, nullptr, stream);
+}
+
+int hydro_step_wrench_tiled_ke(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                               const float* prev, int64_t prev_tile_stride, double dt,
+                               float* wrench, int64_t wrench_tile_stride, int rotational, double* ke_out_dev, void* stream)
+{
+    if (h && !ke_out_dev) return fail(h, HYDRO_E_ARG, "null ke_out_dev");
+    return step_wrench_tiled_impl(h, n, state, state_tile_stride, prev, prev_tile_stride, dt, wrench, wrench_tile_stride,
+                                  rotational ? 1 : 0, ke_out_dev, stream);
 }
 
 int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t in_tile_stride,
@@ -1353,8 +1749,7 @@ int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t 
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { a.si[f] = state_in + f * HYDRO_TILE; a.so[f] = state_out + f * HYDRO_TILE; }
     for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) a.w[f] = wrench + f * HYDRO_TILE;
     a.si_stride = (uint32_t)in_tile_stride; a.w_stride = (uint32_t)wrench_tile_stride; a.so_stride = (uint32_t)out_tile_stride;
-    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
-    a.mass = h->params + 10 * h->stride;
+    a.prm = h->params_tiled; a.prm_tile_floats = prm_tile_floats(h); a.mass_field = prm_mass_field(h);
     a.shift = 6; a.mask = 63u; a.g = h->g; a.dt = (float)dt; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipLaunchKernelGGL(integrate_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a);
@@ -1362,10 +1757,14 @@ int hydro_integrate_tiled(hydro_t* h, int64_t n, const float* state_in, int64_t 
     return HYDRO_OK;
 }
 
-int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
-                           const float* prev, int64_t prev_tile_stride, double dt,
-                           float* state_out, int64_t out_tile_stride,
-                           float* wrench, int64_t wrench_tile_stride, int implicit_drag, void* stream)
+}  // extern "C"
+
+namespace {
+// hydro_step_fused_tiled, optionally sampling the kinetic energy of the state it writes (ke_out != nullptr)
+int step_fused_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                          const float* prev, int64_t prev_tile_stride, double dt,
+                          float* state_out, int64_t out_tile_stride,
+                          float* wrench, int64_t wrench_tile_stride, int implicit_drag, int ke_rotational, double* ke_out, void* stream)
 {
     int rc = check_common(h, n);
     if (rc) return rc;
@@ -1375,7 +1774,9 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     if ((rc = check_tiled(h, n, state_out, out_tile_stride, HYDRO_STATE_FIELDS, "null state_out"))) return rc;
     if (wrench && (rc = check_tiled(h, n, wrench, wrench_tile_stride, HYDRO_WRENCH_FIELDS, "null wrench"))) return rc;
     if (state_out == state) return fail(h, HYDRO_E_ARG, "state_out must not alias state (it may alias the previous-state buffer)");
-    if (n == 0) return HYDRO_OK;
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) return ke_out ? ke_finish(h, 0, ke_out, s) : HYDRO_OK;
     FusedArgs fa;
     TiledArgs& a = fa.t;
     a.st = state; a.st_stride = (uint32_t)state_tile_stride;
@@ -1384,19 +1785,43 @@ int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t st
     a.out = wrench; a.out_stride = wrench ? (uint32_t)wrench_tile_stride : 0;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = (uint32_t)n;
     fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = (float)dt;
-    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
-#define HYDRO_FUSED_ARGS a.st, a.pv, a.prm, fa.so, a.out, a.st_stride, a.pv_stride, fa.so_stride, a.out_stride, a.n, a.warp, fa.dt, a.rho, a.g, a.inv_dt
-#define HYDRO_FUSED(HALF, NT) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true>), grid, blk, 0, s, HYDRO_FUSED_ARGS); \
-                                   else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false>), grid, blk, 0, s, HYDRO_FUSED_ARGS); } while (0)
+#define HYDRO_FUSED_ARGS a.st, a.pv, a.prm, fa.so, a.out, a.st_stride, a.pv_stride, fa.so_stride, a.out_stride, a.n, a.warp, fa.dt, a.rho, a.g, a.inv_dt, \
+        h->ke_partials, h->ke_stride, ke_rotational
+#define HYDRO_FUSED_I(HALF, NT, KE) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true, KE>), grid, blk, 0, s, HYDRO_FUSED_ARGS); \
+                                         else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false, KE>), grid, blk, 0, s, HYDRO_FUSED_ARGS); } while (0)
+#define HYDRO_FUSED(HALF, NT) do { if (ke_out) HYDRO_FUSED_I(HALF, NT, true); else HYDRO_FUSED_I(HALF, NT, false); } while (0)
     if (h->half_coeffs) { if (nt) HYDRO_FUSED(true, true); else HYDRO_FUSED(true, false); }
     else { if (nt) HYDRO_FUSED(false, true); else HYDRO_FUSED(false, false); }
 #undef HYDRO_FUSED
+#undef HYDRO_FUSED_I
 #undef HYDRO_FUSED_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    return HYDRO_OK;
+    return ke_out ? ke_finish(h, n, ke_out, s) : HYDRO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hydro_step_fused_tiled(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                           const float* prev, int64_t prev_tile_stride, double dt,
+                           float* state_out, int64_t out_tile_stride,
+                           float* wrench, int64_t wrench_tile_stride, int implicit_drag, void* stream)
+{
+    return step_fused_tiled_impl(h, n, state, state_tile_stride, prev, prev_tile_stride, dt, state_out, out_tile_stride,
+                                 wrench, wrench_tile_stride, implicit_drag, 0, nullptr, stream);
+}
+
+int hydro_step_fused_tiled_ke(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                              const float* prev, int64_t prev_tile_stride, double dt,
+                              float* state_out, int64_t out_tile_stride,
+                              float* wrench, int64_t wrench_tile_stride, int implicit_drag,
+                              int rotational, double* ke_out_dev, void* stream)
+{
+    if (h && !ke_out_dev) return fail(h, HYDRO_E_ARG, "null ke_out_dev");
+    return step_fused_tiled_impl(h, n, state, state_tile_stride, prev, prev_tile_stride, dt, state_out, out_tile_stride,
+                                 wrench, wrench_tile_stride, implicit_drag, rotational ? 1 : 0, ke_out_dev, stream);
 }
 
 int hydro_pack_state_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,
@@ -1473,6 +1898,15 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     const int grid = grid_for(n, kBlock);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
 #define HYDRO_AOS_ARGS a.pos, a.quat, a.vel, a.force, a.torque, a.pv, a.prm, a.quat_xyzw, (uint32_t)a.n, a.warp, a.rho, a.g, a.inv_dt
+#if !HYDRO_AB_AOS_LDS
+    if (h->half_coeffs) {
+        if (nt) hipLaunchKernelGGL((wrench_aos_direct_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
+        else hipLaunchKernelGGL((wrench_aos_direct_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
+    } else {
+        if (nt) hipLaunchKernelGGL((wrench_aos_direct_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
+        else hipLaunchKernelGGL((wrench_aos_direct_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
+    }
+#else
     if (h->half_coeffs) {
         if (nt) hipLaunchKernelGGL((wrench_aos_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
         else hipLaunchKernelGGL((wrench_aos_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
@@ -1480,6 +1914,7 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
         if (nt) hipLaunchKernelGGL((wrench_aos_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
         else hipLaunchKernelGGL((wrench_aos_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
     }
+#endif
 #undef HYDRO_AOS_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
@@ -1497,10 +1932,11 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
     for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) { if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field"); a.st[f] = state[f]; }
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) { if (!accel[f]) return fail(h, HYDRO_E_ARG, "null acceleration field"); a.acc[f] = accel[f]; }
     for (int f = 0; f < HYDRO_COMP_FIELDS; ++f) { if (!comps[f]) return fail(h, HYDRO_E_ARG, "null component field"); a.out[f] = comps[f]; }
-    fill_params(h, a);
-    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = ensure_soa_params(h, s))) return rc;
+    fill_params(h, a);
+    a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = n;
     const int grid = grid_for(n, kBlock);
     if (h->half_coeffs) hipLaunchKernelGGL(components_kernel<true>, dim3(grid), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL(components_kernel<false>, dim3(grid), dim3(kBlock), 0, s, a);
@@ -1510,17 +1946,12 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
 
 static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, double* out_dev, void* stream)
 {
-    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
-    a.mass = h->params + 10 * h->stride;
-    a.partials = h->ke_partials; a.out = out_dev; a.rotational = rotational; a.n = n;
+    a.prm = h->params_tiled; a.prm_tile_floats = prm_tile_floats(h); a.mass_field = prm_mass_field(h);
+    a.partials = h->ke_partials; a.partial_stride = h->ke_stride; a.rotational = rotational; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int blocks = grid_for(n > 0 ? n : 1, kBlock);
-    if (blocks > kKeBlocks) blocks = kKeBlocks;
-    hipLaunchKernelGGL(ke_partial_kernel, dim3(blocks), dim3(kBlock), 0, s, a);
-    hipLaunchKernelGGL(ke_final_kernel, dim3(1), dim3(kBlock), 0, s, h->ke_partials, blocks, out_dev);
-    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    return HYDRO_OK;
+    if (n > 0) hipLaunchKernelGGL(ke_partial_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);
+    return ke_finish(h, n, out_dev, s);
 }
 
 int hydro_step_components_aos(hydro_t* h, int64_t n, const float* position, const float* orientation_xyzw,
@@ -1587,8 +2018,7 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
         a.si[f] = state_in[f]; a.so[f] = state_out[f];
     }
     for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) { if (!wrench[f]) return fail(h, HYDRO_E_ARG, "null wrench field"); a.w[f] = wrench[f]; }
-    for (int f = 0; f < 3; ++f) a.dims[f] = h->params + f * h->stride;
-    a.mass = h->params + 10 * h->stride;
+    a.prm = h->params_tiled; a.prm_tile_floats = prm_tile_floats(h); a.mass_field = prm_mass_field(h);
     a.si_stride = a.w_stride = a.so_stride = 0; a.shift = 31; a.mask = 0xffffffffu;
     a.g = h->g; a.dt = (float)dt; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);

@@ -117,6 +117,12 @@ class HydroEngine:
         self.n = n
         self.coeff_dtype = coeff_dtype
 
+    def reserve_soa(self) -> None:
+        """Make the engine's plain-SoA copies of the parameters / previous velocity now (82 B per body).  They are
+        otherwise made by the first call of an entry that takes plain field pointers (`step_wrench`, `step_components`),
+        which then allocates and synchronises once - call this first if that call is to be captured into a HIP graph."""
+        self._check(self._lib.hydro_reserve_soa(self._h))
+
     def set_tuning(self, bodies_per_lane: int = 0, block_threads: int = 0, non_temporal: int = -1,
                    waves_per_simd: int = -1) -> None:
         self._check(self._lib.hydro_set_tuning(self._h, bodies_per_lane, block_threads, non_temporal, waves_per_simd))
@@ -184,12 +190,19 @@ class HydroEngine:
         self._check(self._lib.hydro_repack(self._h, n, f, self._table(out, f), tiled.data_ptr(), f * nat.TILE, 0, self._stream(stream)))
         return out
 
+    def _check_ke_out(self, ke_out: torch.Tensor) -> None:
+        if ke_out.dtype != torch.float64 or ke_out.device != self.device or ke_out.numel() < 2 or not ke_out.is_contiguous():
+            raise ValueError(f"ke_out: expected a contiguous float64 tensor of 2 elements on {self.device}")
+
     def step_wrench_tiled(self, state: torch.Tensor, n: int, dt: float, out: torch.Tensor | None = None,
-                          prev: torch.Tensor | None = None, stream=None) -> torch.Tensor:
+                          prev: torch.Tensor | None = None, stream=None, ke_out: torch.Tensor | None = None,
+                          rotational: bool = True) -> torch.Tensor:
         """Fused wrench on tiled buffers: state (tiles,13,64) -> out (tiles,6,64).
         prev: None = engine-owned previous velocity (read + updated); a (tiles,6,64) tensor; or a
         (tiles,13,64) STATE tensor whose velocity fields are used in place (ping-pong integrator:
-        pass the previous step's state buffer - nothing is copied)."""
+        pass the previous step's state buffer - nothing is copied).
+        ke_out (float64, 2 elements, on the device): the kernel also samples the kinetic energy of `state` - the
+        bodies it holds in registers anyway, no second pass - into ke_out[0:2] = [translational, rotational]."""
         self._check_tiled(state, nat.STATE_FIELDS, n)
         if out is None:
             out = self.alloc_tiled(nat.WRENCH_FIELDS, n)
@@ -202,13 +215,20 @@ class HydroEngine:
         else:
             self._check_tiled(prev, nat.PREV_FIELDS, n)
             p_ptr, p_stride = prev.data_ptr(), nat.PREV_FIELDS * nat.TILE
-        self._check(self._lib.hydro_step_wrench_tiled(
-            self._h, n, state.data_ptr(), nat.STATE_FIELDS * nat.TILE, p_ptr, p_stride, float(dt),
-            out.data_ptr(), nat.WRENCH_FIELDS * nat.TILE, self._stream(stream)))
+        if ke_out is None:
+            self._check(self._lib.hydro_step_wrench_tiled(
+                self._h, n, state.data_ptr(), nat.STATE_FIELDS * nat.TILE, p_ptr, p_stride, float(dt),
+                out.data_ptr(), nat.WRENCH_FIELDS * nat.TILE, self._stream(stream)))
+        else:
+            self._check_ke_out(ke_out)
+            self._check(self._lib.hydro_step_wrench_tiled_ke(
+                self._h, n, state.data_ptr(), nat.STATE_FIELDS * nat.TILE, p_ptr, p_stride, float(dt),
+                out.data_ptr(), nat.WRENCH_FIELDS * nat.TILE, int(bool(rotational)), ke_out.data_ptr(), self._stream(stream)))
         return out
 
     def prepare_step_wrench_tiled(self, state: torch.Tensor, n: int, dt: float, out: torch.Tensor | None = None,
-                                  prev: torch.Tensor | None = None, stream=None):
+                                  prev: torch.Tensor | None = None, stream=None, ke_out: torch.Tensor | None = None,
+                                  rotational: bool = True):
         """Validate the arguments of `step_wrench_tiled` ONCE and return a zero-argument callable that issues
         that launch again (same buffers, same stream - the one current now if `stream` is None).  For step
         loops over small scenes, where the per-call Python work (shape checks, ctypes conversions: ~10 us)
@@ -226,11 +246,17 @@ class HydroEngine:
         else:
             self._check_tiled(prev, nat.PREV_FIELDS, n)
             p_ptr, p_stride = prev.data_ptr(), nat.PREV_FIELDS * nat.TILE
-        fn = self._lib.hydro_step_wrench_tiled
         args = (self._h, ctypes.c_int64(n), ctypes.c_void_p(state.data_ptr()), ctypes.c_int64(nat.STATE_FIELDS * nat.TILE),
                 ctypes.c_void_p(p_ptr), ctypes.c_int64(p_stride), ctypes.c_double(float(dt)),
-                ctypes.c_void_p(out.data_ptr()), ctypes.c_int64(nat.WRENCH_FIELDS * nat.TILE), self._stream(stream))
-        keep = (state, prev, out)                       # the buffers must outlive the callable
+                ctypes.c_void_p(out.data_ptr()), ctypes.c_int64(nat.WRENCH_FIELDS * nat.TILE))
+        if ke_out is None:
+            fn = self._lib.hydro_step_wrench_tiled
+            args = args + (self._stream(stream),)
+        else:                                           # the variant that samples the kinetic energy of `state` on the way
+            self._check_ke_out(ke_out)
+            fn = self._lib.hydro_step_wrench_tiled_ke
+            args = args + (ctypes.c_int(int(bool(rotational))), ctypes.c_void_p(ke_out.data_ptr()), self._stream(stream))
+        keep = (state, prev, out, ke_out)               # the buffers must outlive the callable
         check = self._check
 
         def step():
@@ -244,9 +270,11 @@ class HydroEngine:
 
     def step_fused_tiled(self, state: torch.Tensor, prev_state: torch.Tensor, n: int, dt: float,
                          state_out: torch.Tensor | None = None, wrench: torch.Tensor | None = None,
-                         implicit_drag: bool = False, stream=None):
+                         implicit_drag: bool = False, stream=None, ke_out: torch.Tensor | None = None,
+                         rotational: bool = True):
         """Wrench + integrator in one kernel.  `prev_state` (tiles,13,64) supplies the previous velocity;
-        `state_out` defaults to `prev_state` itself (ping-pong: the old buffer receives the new state)."""
+        `state_out` defaults to `prev_state` itself (ping-pong: the old buffer receives the new state).
+        ke_out (float64, 2 elements, device): also sample the kinetic energy of the NEW state into it."""
         self._check_tiled(state, nat.STATE_FIELDS, n)
         self._check_tiled(prev_state, nat.STATE_FIELDS, n)
         if state_out is None:
@@ -257,9 +285,16 @@ class HydroEngine:
             self._check_tiled(wrench, nat.WRENCH_FIELDS, n)
             w_ptr, w_stride = wrench.data_ptr(), nat.WRENCH_FIELDS * nat.TILE
         st = nat.STATE_FIELDS * nat.TILE
-        self._check(self._lib.hydro_step_fused_tiled(
-            self._h, n, state.data_ptr(), st, prev_state.data_ptr() + 7 * nat.TILE * 4, st, float(dt),
-            state_out.data_ptr(), st, w_ptr, w_stride, int(bool(implicit_drag)), self._stream(stream)))
+        if ke_out is None:
+            self._check(self._lib.hydro_step_fused_tiled(
+                self._h, n, state.data_ptr(), st, prev_state.data_ptr() + 7 * nat.TILE * 4, st, float(dt),
+                state_out.data_ptr(), st, w_ptr, w_stride, int(bool(implicit_drag)), self._stream(stream)))
+        else:
+            self._check_ke_out(ke_out)
+            self._check(self._lib.hydro_step_fused_tiled_ke(
+                self._h, n, state.data_ptr(), st, prev_state.data_ptr() + 7 * nat.TILE * 4, st, float(dt),
+                state_out.data_ptr(), st, w_ptr, w_stride, int(bool(implicit_drag)), int(bool(rotational)),
+                ke_out.data_ptr(), self._stream(stream)))
         return state_out
 
     def integrate_tiled(self, state_in: torch.Tensor, wrench: torch.Tensor, n: int, dt: float,

@@ -26,8 +26,10 @@ class KineticEnergyMonitor:
     """The one collective of the path: global kinetic energy, off the step path.
 
     Every `every` steps the rank's shard is reduced ON DEVICE to one float64 pair [translational, rotational]
-    (`hydro_kinetic_energy*`: wave64 shuffles -> LDS -> one partial per block -> fixed-order second stage), on
-    the stream the steps run on.  The pair is then summed over the ranks on a SIDE stream -
+    (wave64 shuffles -> LDS -> one partial per block -> fixed-order second stage), on the stream the steps run on -
+    either INSIDE the step kernel, for the bodies it holds in registers anyway (`hydro_step_*_tiled_ke`: the caller
+    passes the pair as `sampled=`; no second pass over the state), or by the stand-alone `hydro_kinetic_energy*` on
+    the state passed to `observe`.  The pair is then summed over the ranks on a SIDE stream -
     `all_reduce(async_op=True)`, RCCL over xGMI under backend "nccl" (16 bytes: latency, not bandwidth), gloo on a
     pinned host copy otherwise - and copied to pinned host memory.  The step stream never waits for any of it; the
     host picks a sample up `every` steps later (`collect()`), when it has long arrived.  The reference has no
@@ -40,8 +42,11 @@ class KineticEnergyMonitor:
                  device: torch.device | str | None = None, reduce_local=None):
         if every <= 0 or slots < 2:
             raise ValueError("every must be positive, slots at least 2")
+        if engine is None and device is None:
+            raise ValueError("KineticEnergyMonitor needs an engine, or a device (with reduce_local=, or with observe(..., sampled=))")
         self.engine, self.every, self.rotational = engine, int(every), bool(rotational)
         self.device = torch.device(device) if device is not None else engine.device
+        self._copied = None                   # event: the side stream has taken its copy of the last `sampled` buffer
         self._reduce_local = reduce_local
         self._gpu = self.device.type == "cuda"
         self._nccl = self._gpu and hd.collective_device(self.device).type == "cuda"
@@ -54,11 +59,20 @@ class KineticEnergyMonitor:
         self.submitted = 0
         self.waited_on_host = 0               # samples the host had to wait for (0 when `every` covers the latency)
 
-    def observe(self, step: int, state: torch.Tensor | None = None, stream=None) -> bool:
-        """Call after physics step `step` (1-based count of completed steps) with the state that step produced.
+    def wait_before_overwrite(self, stream=None) -> None:
+        """Order `stream` after the side stream's copy of the last `sampled` buffer: call before launching the next
+        step that writes that buffer (an event wait on the device; it has fired long before, the host never blocks)."""
+        if self._copied is not None and self._gpu:
+            (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._copied)
+
+    def observe(self, step: int, state: torch.Tensor | None = None, stream=None, sampled: torch.Tensor | None = None) -> bool:
+        """Call after physics step `step` (1-based count of completed steps) with the state that step produced - or
+        with `sampled`, the float64 pair a sampling step kernel (ke_out=) has already written on `stream`.
         Submits a sample when `step` is a multiple of `every`; returns True if it did."""
         if step % self.every:
             return False
+        if sampled is None and state is None and self._reduce_local is None:
+            raise ValueError("observe() needs the state, a sampled pair, or a reduce_local callback")
         self.collect(block_oldest=len(self._pending) >= len(self._dev) - 1)      # free a slot if the ring is full
         slot = self._next_slot
         self._next_slot = (slot + 1) % len(self._dev)
@@ -66,12 +80,17 @@ class KineticEnergyMonitor:
         if self._gpu:
             stream = stream if stream is not None else torch.cuda.current_stream(self.device)
             with torch.cuda.stream(stream):
-                self._local(state, dev_buf)
+                if sampled is None:
+                    self._local(state, dev_buf)
                 ready = torch.cuda.Event()
                 ready.record(stream)
             self._side.wait_event(ready)                    # the side stream, not the host, waits for the reduction
             work = None
             with torch.cuda.stream(self._side):
+                if sampled is not None:                     # 16 bytes, device to device, on the SIDE stream
+                    dev_buf.copy_(sampled[:2], non_blocking=True)
+                    self._copied = torch.cuda.Event()
+                    self._copied.record(self._side)
                 if self._nccl:
                     work = hd.all_reduce_sum_(dev_buf, async_op=True)
                     if work is not None:
@@ -81,7 +100,10 @@ class KineticEnergyMonitor:
                 done.record(self._side)
             self._pending.append((step, slot, None if self._nccl else "gloo", done))
         else:
-            self._local(state, dev_buf)
+            if sampled is not None:
+                dev_buf.copy_(sampled[:2])
+            else:
+                self._local(state, dev_buf)
             host_buf.copy_(dev_buf)
             self._pending.append((step, slot, hd.all_reduce_sum_(host_buf, async_op=True), None))
         self.submitted += 1
@@ -146,50 +168,66 @@ class ClosedLoopSim:
         self.steps_done = 0
         self._graph = None
         self._graph_steps = 0
-        # optional global kinetic energy every `ke_every` steps (asynchronous, see KineticEnergyMonitor); with HIP-graph
-        # replays the sampling points are the replay boundaries, so `ke_every` should be a multiple of graph_steps
+        # optional global kinetic energy every `ke_every` steps (asynchronous, see KineticEnergyMonitor).  The fused
+        # step SAMPLES it for the bodies it has in registers (ke_out=): no extra pass over the state.  With HIP-graph
+        # replays the sampling step is the last step of the graph, so `ke_every` must be a multiple of graph_steps.
         self.monitor = KineticEnergyMonitor(self.engine, every=ke_every) if ke_every else None
+        self.ke_dev = torch.zeros(2, dtype=torch.float64, device=dev) if ke_every else None
 
-    # one physics step on the current stream context
-    def _step_once(self) -> None:
+    # one physics step on the current stream context; sample=True: the step also leaves the kinetic energy of the state it
+    # produces in self.ke_dev (fused step: inside the kernel; two-kernel path: the stand-alone reduction afterwards)
+    def _step_once(self, sample: bool = False) -> None:
         e = self.engine
         if self.fused:
-            e.step_fused_tiled(self.cur, self.old, self.n, self.dt, implicit_drag=self.implicit_drag)   # new state -> old buffer
+            e.step_fused_tiled(self.cur, self.old, self.n, self.dt, implicit_drag=self.implicit_drag,
+                               ke_out=self.ke_dev if sample else None)                              # new state -> old buffer
         else:
             e.step_wrench_tiled(self.cur, self.n, self.dt, out=self.wrench, prev=self.old)
             e.integrate_tiled(self.cur, self.wrench, self.n, self.dt, state_out=self.old)   # overwrite the old buffer
+            if sample:
+                e.kinetic_energy(self.old, True, out=self.ke_dev)
         self.cur, self.old = self.old, self.cur
 
     def run_eager(self, steps: int) -> None:
         with torch.cuda.stream(self.stream):
             for _ in range(steps):
-                self._step_once()
+                sample = self.monitor is not None and (self.steps_done + 1) % self.monitor.every == 0
+                if sample:
+                    self.monitor.wait_before_overwrite(self.stream)
+                self._step_once(sample)
                 self.steps_done += 1
-                if self.monitor:
-                    self.monitor.observe(self.steps_done, self.cur, self.stream)
+                if sample:
+                    self.monitor.observe(self.steps_done, stream=self.stream, sampled=self.ke_dev)
 
     def _capture(self, graph_steps: int) -> None:
         if graph_steps % 2:
             raise ValueError("graph_steps must be even (the ping-pong must return to the same buffers)")
+        if self.monitor is not None and self.monitor.every % graph_steps:
+            raise ValueError(f"ke_every ({self.monitor.every}) must be a multiple of graph_steps ({graph_steps}): with graph "
+                             f"replays the kinetic energy is sampled by the last step of a replay")
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(self.stream):
             self.stream.synchronize()
             with torch.cuda.graph(g, stream=self.stream):
-                for _ in range(graph_steps):
-                    self._step_once()
+                for k in range(graph_steps):
+                    self._step_once(sample=self.monitor is not None and k == graph_steps - 1)
         self._graph, self._graph_steps = g, graph_steps
 
     def run(self, steps: int, graph_steps: int = 64) -> None:
         """Advance `steps` physics steps; full groups of `graph_steps` are graph replays."""
         if graph_steps and steps >= graph_steps:
+            if self.steps_done % graph_steps and self.monitor is not None:
+                raise ValueError("with a kinetic-energy monitor, graph replays must start at a multiple of graph_steps")
             if self._graph is None or self._graph_steps != graph_steps:
                 self._capture(graph_steps)              # capturing records, it does not execute
             with torch.cuda.stream(self.stream):
                 for _ in range(steps // graph_steps):
+                    if self.monitor:
+                        self.monitor.wait_before_overwrite(self.stream)
                     self._graph.replay()
                     self.steps_done += graph_steps
                     if self.monitor:
-                        self.monitor.observe(self.steps_done, self.cur, self.stream)
+                        self.monitor.observe(self.steps_done, stream=self.stream, sampled=self.ke_dev)
             steps %= graph_steps
         if steps:
             self.run_eager(steps)

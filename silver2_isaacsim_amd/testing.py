@@ -21,6 +21,7 @@ class FakeWorld:
     def __init__(self, device: str = "cuda:0"):
         self.device = torch.device(device)
         self.paths: list[str] = []
+        self._index: dict[str, int] = {}
         self.positions = torch.zeros((0, 3), device=self.device)
         self.orientations = torch.zeros((0, 4), device=self.device)     # wxyz
         self.velocities = torch.zeros((0, 6), device=self.device)
@@ -38,7 +39,9 @@ class FakeWorld:
         return len(self.paths) - 1
 
     def index(self, path: str) -> int:
-        return self.paths.index(path)
+        if len(self._index) != len(self.paths):         # paths appended in bulk (build_c3_scene)
+            self._index = {p: i for i, p in enumerate(self.paths)}
+        return self._index[path]
 
 
 class _Applied:
@@ -63,7 +66,14 @@ class FakeRigidView:
     out the SAME device buffers every physics step (refreshed in place from the world's state), and it consumes the
     applied wrench with two device copies."""
 
-    def __init__(self, world: FakeWorld, prim_paths: Sequence[str], name: str):
+    def __init__(self, world: FakeWorld, prim_paths: Sequence[str], name: str, buffers: str = "stable"):
+        """buffers: what `get_world_poses / get_velocities(clone=False)` hand out -
+        "stable" the same device tensors every step (a tensor API's views; the best case for the plugin's prepared
+        launch), "fresh" newly allocated tensors every step, "strided" non-contiguous views of wider tensors,
+        "numpy" host NumPy arrays (a view created without the torch backend, hydrodynamics_behavior.py:50-51)."""
+        if buffers not in ("stable", "fresh", "strided", "numpy"):
+            raise ValueError(buffers)
+        self.buffers = buffers
         self.world, self.name = world, name
         self.idx = torch.tensor([world.index(p) for p in prim_paths], dtype=torch.long, device=world.device)
         self.paths = list(prim_paths)
@@ -87,18 +97,30 @@ class FakeRigidView:
             raise RuntimeError("simulated tensor API failure")
         torch.index_select(self.world.positions, 0, self.idx, out=self._pos)
         torch.index_select(self.world.orientations, 0, self.idx, out=self._quat)
-        return (self._pos.clone(), self._quat.clone()) if clone else (self._pos, self._quat)
+        if clone or self.buffers != "stable":
+            return self._hand_out(self._pos), self._hand_out(self._quat)
+        return self._pos, self._quat
 
     def get_velocities(self, clone=False):
         torch.index_select(self.world.velocities, 0, self.idx, out=self._vel)
-        return self._vel.clone() if clone else self._vel
+        return self._hand_out(self._vel) if clone or self.buffers != "stable" else self._vel
+
+    def _hand_out(self, t: torch.Tensor):
+        if self.buffers == "numpy":
+            return t.cpu().numpy()
+        if self.buffers == "strided":                   # every row padded by one column: same values, not contiguous
+            wide = torch.empty((t.shape[0], t.shape[1] + 1), device=t.device, dtype=t.dtype)
+            wide[:, :t.shape[1]] = t
+            return wide[:, :t.shape[1]]
+        return t.clone()
 
     def get_masses(self, clone=False):
-        return self.world.masses[self.idx]
+        m = self.world.masses[self.idx]
+        return m.cpu().numpy() if self.buffers == "numpy" else m
 
     def apply_forces_and_torques_at_pos(self, forces=None, torques=None, positions=None, is_global=True):
         self.world.apply_calls += 1
-        if self._force is None:
+        if self._force is None or self._force.shape != forces.shape:
             self._force, self._torque = torch.empty_like(forces), torch.empty_like(torques)
             for k, p in enumerate(self.paths):
                 self.world.applied._where[p] = (self, k)
@@ -110,21 +132,35 @@ class FakeHost:
     """`SimHost` over a FakeWorld; `step(dt)` fires every subscribed physics-step callback
     once, in subscription order, like Kit does."""
 
-    def __init__(self, world: FakeWorld, config_path: str | None = None):
+    def __init__(self, world: FakeWorld, config_path: str | None = None, view_buffers: str = "stable"):
         self.world = world
         self.device = str(world.device)
         self._config_path = config_path
         self._subs: list[Callable[[float], None]] = []
         self.views: list[FakeRigidView] = []
+        self.view_buffers = view_buffers
+        self.lifecycle: list[str] = []                  # what the plugin asked of "Kit", in order (tests read it)
+        self.callbacks_fired = 0
+
+    # the two Kit calls of the reference's lifecycle besides the variable store (:50-51, :70, :126)
+    def ensure_simulation_context(self):
+        self.lifecycle.append("simulation_context(torch)")
+        return self
+
+    def request_property_rebuild(self):
+        self.lifecycle.append("request_rebuild")
 
     # exposed variables
     def create_exposed_variables(self, prim: AttributeStore, variables):
+        self.lifecycle.append("create_exposed_variables")
         for v in variables:
             prim.create(cfg.full_attr_name(v["attr_name"]), v["default_value"])
 
     def remove_exposed_variables(self, prim: AttributeStore, variables):
+        self.lifecycle.append("remove_exposed_variables")
         for v in variables:
             prim.remove(cfg.full_attr_name(v["attr_name"]))
+        return True
 
     def get_exposed_variable(self, prim: AttributeStore, full_attr_name: str) -> float:
         return prim.get(full_attr_name)
@@ -139,7 +175,7 @@ class FakeHost:
         return prim.path
 
     def make_rigid_view(self, prim_paths, name):
-        v = FakeRigidView(self.world, prim_paths, name)
+        v = FakeRigidView(self.world, prim_paths, name, self.view_buffers)
         self.views.append(v)
         return v
 
@@ -147,25 +183,31 @@ class FakeHost:
         self._subs.append(callback)
         return callback
 
+    def unsubscribe_physics_step(self, token):
+        if token in self._subs:
+            self._subs.remove(token)
+
     def config_path(self):
         return self._config_path
 
     def step(self, dt: float):
         for cb in list(self._subs):
+            self.callbacks_fired += 1
             cb(dt)
 
 
 MAIN_SCENE = ["Obsea_Buoy", "Body"] + [f"{p}_{i}" for p in ("Coxa", "Femur", "Tibia") for i in range(6)]
 
 
-def build_main_scene(batched: bool = True, config_path: str | None = None, seed: int = 0, device: str = "cuda:0"):
+def build_main_scene(batched: bool | str = True, config_path: str | None = None, seed: int = 0, device: str = "cuda:0",
+                     view_buffers: str = "stable"):
     """The 20 prims of silver2_isaac_sim.usd that carry the behavior, each with its own
     `HydrodynamicsBehavior` on an in-memory host: (world, host, prims, behaviors), `on_init` done."""
     import numpy as np
     from . import behavior as hb
     rng = np.random.default_rng(seed)
     world = FakeWorld(device)
-    host = FakeHost(world, config_path)
+    host = FakeHost(world, config_path, view_buffers)
     prims, behaviors = [], []
     for name in MAIN_SCENE:
         buoy = name == "Obsea_Buoy"
@@ -183,3 +225,31 @@ def build_main_scene(batched: bool = True, config_path: str | None = None, seed:
                 host.set_exposed_variable(prim, cfg.full_attr_name(k), v)
         prims.append(prim); behaviors.append(b)
     return world, host, prims, behaviors
+
+
+def build_c3_scene(envs: int = 1024, batched: bool | str = True, seed: int = 3, device: str = "cuda:0"):
+    """BASELINE config 3 through the PLUGIN: `envs` SILVER2 robots (body + 6 coxae + 6 femora + 6 tibiae = 19 prims each;
+    19 456 prims at 1 024 envs), every prim with its own `HydrodynamicsBehavior`, parameters from the JSON part table,
+    masses as in silver2_isaac_sim.usd.  (world, host, prims, behaviors), `on_init` done."""
+    import numpy as np
+    from . import behavior as hb
+    from . import scenes
+    sc = scenes.scene_c3(envs=envs, seed=seed)
+    world = FakeWorld(device)
+    dev = world.device
+    st = sc.state
+    world.positions = torch.from_numpy(np.ascontiguousarray(st[:, 0:3])).to(dev)
+    world.orientations = torch.from_numpy(np.ascontiguousarray(st[:, [6, 3, 4, 5]])).to(dev)
+    world.velocities = torch.from_numpy(np.ascontiguousarray(st[:, 7:13])).to(dev)
+    world.masses = torch.from_numpy(np.ascontiguousarray(sc.params[:, 10])).to(dev)
+    host = FakeHost(world)
+    links = ["Body"] + [f"{p}_{i}" for p in ("Coxa", "Femur", "Tibia") for i in range(6)]
+    prims, behaviors = [], []
+    for e in range(envs):
+        for name in links:
+            prim = AttributeStore(name, f"/World/envs/env_{e}/SILVER2/{name}")
+            world.paths.append(prim.path)
+            b = hb.HydrodynamicsBehavior(prim, host, batched=batched)
+            b.on_init()
+            prims.append(prim); behaviors.append(b)
+    return world, host, prims, behaviors, sc

@@ -28,6 +28,11 @@ def test_bench_json_contract(native_built):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    # ONE clock: `frac` is on the interval `value` and `ms_per_step` come from (bytes per launch / ms_per_step) ...
+    assert r["frac"] * r["peak"] * 1e9 * d["ms_per_step"] * 1e-3 == pytest.approx(r["algorithmic_bytes_per_launch"], rel=1e-9)
+    assert d["value"] == pytest.approx(65536 / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    # ... and the HIP-event figure of the same steps is kept beside it (shorter: no host synchronisation in it)
+    assert r["frac_contract_steps"] >= r["frac"] and r["kernel_us"] <= r["step_us"] * 1.0001
     assert r["traffic_bytes_per_body"] == 122 and r["frac_traffic"] == pytest.approx(r["frac"] * 122 / 130)
     assert r["resident"] in ("hbm", "infinity-cache") and "roofline_4m" not in d      # 65 536 bodies x 4: a cache-resident test size
     c = d["cpu_baseline"]
@@ -81,3 +86,31 @@ def test_bench_two_ranks_share_the_gpu(native_built):
     m = sc.params[:, 10].astype(np.float64)
     lin = float((0.5 * m * (sc.state[:, 7:10].astype(np.float64) ** 2).sum(1)).sum())
     assert ke2["global_J"][0] == pytest.approx(lin, rel=1e-12)
+
+
+def test_bench_gpus_2_launches_its_own_ranks(native_built):
+    """`python bench.py --gpus 2` with NO torchrun environment must not fall through to a one-GPU run: it starts the two
+    ranks itself (before anything touches the GPU) and relays rank 0's line.  Rehearsed on this box's one GPU with both
+    ranks sharing it and gloo for the collectives."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HYDRO_BENCH_SHARE_GPU="1", HYDRO_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "8", "--bodies", "65536",
+           "--spinup-seconds", "0.2"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collectives"] == "gloo, 2 rank(s)" and "x2" in d["config"]["sharding"]
+    assert d["c4_strong"]["n_gpus"] == 2 and d["c4_strong"]["bodies_this_rank"] == 131072
+
+
+def test_bench_refuses_more_gpus_than_visible(native_built):
+    """--gpus N with fewer than N devices visible (and no rehearsal knob): non-zero exit, a message, no JSON line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HYDRO_BENCH_SHARE_GPU")}
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert f"--gpus {n} but only {n - 1} GPU(s) are visible" in res.stderr

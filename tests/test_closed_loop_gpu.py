@@ -55,7 +55,11 @@ def test_config1_single_buoy_on_the_gpu(native_built):
         z.append(sim.state()[0, 2])
     z = np.array(z)
     ref = fx["z"][99::100]
-    assert np.abs(z - ref).max() < 2e-3, np.abs(z - ref).max()
+    print(f"[config 1 on the GPU] max |z - z_ref| over 10 000 steps: {np.abs(z - ref).max():.3e} m; final offset from the "
+          f"analytic equilibrium {abs(z[-1] - (0.5 - float(fx['mass']) / float(fx['rho']))):.3e} m")
+    # wrench in fp64, state and integrator in fp32; the buoy stays upright, so the only rounding on the way is that of the
+    # fp32 position / velocity updates of a 0.6 m oscillation: measured 6.6e-8 m over the 10 000 steps (was allowed 2e-3)
+    assert np.abs(z - ref).max() < 1e-6, np.abs(z - ref).max()
     assert abs(z[-1] - (0.5 - float(fx["mass"]) / float(fx["rho"]))) < 3e-3
     st = sim.state()[0]
     assert np.abs(st[3:6]).max() < 1e-4 and abs(st[6] - 1) < 1e-6      # the cube stays upright

@@ -205,10 +205,17 @@ def test_component_mode_matches_reference_outputs(name, native_built):
     vol = fx["params"][:, :3].astype(np.float64).prod(1)
     floor = np.maximum(1e-3 * rho * g * vol, 1e-12)[:, None]
     rel = np.linalg.norm(c[:, :6] - ref[:, :6], axis=2) / np.maximum(np.linalg.norm(ref[:, :6], axis=2), floor)
-    assert rel.max() < 5e-5                       # per-component (lift near |d|->1 is the worst)
-    assert np.median(rel) < 3e-7
-    # centres are world-space fp32: half an ulp of |p| (~100 m) = 4e-6
-    assert np.abs(c[:, 6:] - ref[:, 6:]).max() < 1e-5 * max(1.0, np.abs(fx["state"][:, :3]).max() / 50)
+    cen = np.abs(c[:, 6:] - ref[:, 6:]).max()
+    ulp_p = np.spacing(np.float32(np.abs(fx["state"][:, :3]).max() + 2.0))     # centres are world-space fp32 numbers
+    print(f"[components {name}] per-component max {rel.max():.3e} median {np.median(rel):.3e}; centres max {cen:.3e} m (fp32 ulp there {ulp_p:.3e})")
+    # the body is evaluated in fp64 and each component rounded to fp32 ONCE: half an ulp per coordinate, i.e. at most
+    # sqrt(3) * 2^-24 = 1.03e-7 of the component's own norm (a bound, not an allowance; was 5e-5 for the fp32 body).
+    # The K vectors ("kat") are the exception: their inputs are float64 numbers (SURVEY's raw quaternions normalised in
+    # fp64), so handing them to an fp32 interface rounds the INPUTS by 6e-8 and the lift follows with 5e-7.
+    assert rel.max() < (1.1e-7 if name != "kat" else 2e-6)
+    assert np.median(rel) < 6e-8
+    # centres: fp64 lever arm + position, rounded once to a world-space fp32 number: half an ulp of |p|
+    assert cen <= 0.5 * ulp_p * 1.0001
     assert np.abs(ratio.cpu().numpy() - fx["ratio"]).max() < 5e-7
     dry = fx["ratio"] == 0
     assert np.all(c[dry] == 0.0)                  # Numba semantics: cob = cop = 0 when dry (N6)
@@ -286,11 +293,98 @@ def test_kinetic_energy_reduction(native_built):
     lin = ho.kinetic_energy(sc.state, sc.params, False)[0]
     tot = ho.kinetic_energy(sc.state, sc.params, True)[0]
     assert a[0] == pytest.approx(lin, rel=1e-12)                      # fp64 accumulation of exact fp32 products
-    assert a.sum() == pytest.approx(tot, rel=1e-6)
+    assert a.sum() == pytest.approx(tot, rel=1e-12)                   # the rotational term is fp64 per body as well
     only_lin = eng.kinetic_energy(S, rotational=False).cpu().numpy()
     assert only_lin[1] == 0.0 and only_lin[0] == a[0]
     t = eng.kinetic_energy(torch.from_numpy(scenes.to_tiled(sc.state)).to(DEV), rotational=True).cpu().numpy()
     assert np.array_equal(t, a)                                       # tiled layout: same bits
+    eng.close()
+
+
+@pytest.mark.parametrize("coeff", ["f32", "f16"])
+@pytest.mark.parametrize("n", [100003, 257, 64, 1])
+def test_kinetic_energy_sampled_inside_the_step_kernels(coeff, n, native_built):
+    """SURVEY.md 8e "reduced in-kernel": hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke sample the energy of
+    the bodies they hold.  Same wrench / state bits as the plain kernels; the pair has the bits of the stand-alone
+    reduction of the same state (same per-body arithmetic, same decomposition) and equals the fp64 host sum."""
+    sc = scenes.scene_c4(n=n, seed=21)
+    eng = HydroEngine(sc.n, DEV, sc.rho, sc.g)
+    eng.set_params(sc.params, coeff)
+    prm = sc.params.copy()
+    if coeff == "f16":
+        prm[:, 3:10] = prm[:, 3:10].astype(np.float16).astype(np.float32)
+    st, pv = tiled(sc.state), tiled(sc.prev)
+    plain = eng.step_wrench_tiled(st, sc.n, sc.dt, prev=pv)
+    ke = torch.full((2,), -1.0, dtype=torch.float64, device=DEV)
+    sampled = eng.step_wrench_tiled(st, sc.n, sc.dt, prev=pv, ke_out=ke, rotational=True)
+    alone = eng.kinetic_energy(st, rotational=True)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, sampled)                                 # the wrench does not notice
+    assert torch.equal(ke, alone)                                      # in-kernel sample == stand-alone reduction, bit for bit
+    tot = ho.kinetic_energy(sc.state, prm, True)[0]; lin = ho.kinetic_energy(sc.state, prm, False)[0]
+    assert ke[0].item() == pytest.approx(lin, rel=1e-12) and ke.sum().item() == pytest.approx(tot, rel=1e-12)
+    ke_lin = torch.zeros(2, dtype=torch.float64, device=DEV)
+    eng.step_wrench_tiled(st, sc.n, sc.dt, prev=pv, ke_out=ke_lin, rotational=False)
+    torch.cuda.synchronize()
+    assert ke_lin[0].item() == ke[0].item() and ke_lin[1].item() == 0.0
+    # engine-owned previous velocity (the WRITE_PREV kernels) and the prepared form
+    eng.set_prev_velocity(sc.prev); own = eng.step_wrench_tiled(st, sc.n, sc.dt)
+    eng.set_prev_velocity(sc.prev); ke2 = torch.zeros(2, dtype=torch.float64, device=DEV)
+    own_s = eng.step_wrench_tiled(st, sc.n, sc.dt, ke_out=ke2)
+    step = eng.prepare_step_wrench_tiled(st, sc.n, sc.dt, prev=pv, ke_out=torch.zeros(2, dtype=torch.float64, device=DEV))
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(own, own_s) and torch.equal(ke2, ke) and torch.equal(own, plain)
+    # the fused step samples the state it WRITES
+    prev_state = np.zeros_like(sc.state); prev_state[:, 7:13] = sc.prev
+    for implicit in (False, True):
+        old_a, old_b = tiled(prev_state), tiled(prev_state)
+        kf = torch.zeros(2, dtype=torch.float64, device=DEV)
+        new_plain = eng.step_fused_tiled(st, old_a, sc.n, sc.dt, implicit_drag=implicit)
+        new_sampled = eng.step_fused_tiled(st, old_b, sc.n, sc.dt, implicit_drag=implicit, ke_out=kf)
+        alone_new = eng.kinetic_energy(new_plain, rotational=True)
+        torch.cuda.synchronize()
+        assert torch.equal(new_plain, new_sampled) and torch.equal(kf, alone_new)
+        host_new = ho.kinetic_energy(scenes.from_tiled(new_plain.cpu().numpy(), sc.n), prm, True)[0]
+        assert kf.sum().item() == pytest.approx(host_new, rel=1e-12)
+    with pytest.raises(ValueError):
+        eng.step_wrench_tiled(st, sc.n, sc.dt, prev=pv, ke_out=torch.zeros(2, device=DEV))     # float32: refused
+    eng.close()
+
+
+def test_engine_holds_68_bytes_per_body_until_a_plain_soa_entry_is_used(native_built):
+    """The engine's own buffers: tiled parameters (44 B) + tiled previous velocity (24 B) per body of capacity.  The
+    plain-SoA copies (82 B more) appear with the first call of an entry point that takes plain field pointers."""
+    cap = 1 << 22
+    fx = load_golden("c2")
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    eng = HydroEngine(cap, DEV)
+    eng.set_params(fx["params"][:4096], "f16")
+    st = tiled(fx["state"]); pv = tiled(fx["prev"])
+    w = eng.step_wrench_tiled(st, 4096, float(fx["dt"]), prev=pv)
+    eng.step_wrench_tiled(st, 4096, float(fx["dt"]))                              # engine-owned previous velocity
+    pos = torch.from_numpy(np.ascontiguousarray(fx["state"][:, 0:3])).to(DEV)
+    quat = torch.from_numpy(np.ascontiguousarray(fx["state"][:, 3:7])).to(DEV)
+    vel = torch.from_numpy(np.ascontiguousarray(fx["state"][:, 7:13])).to(DEV)
+    eng.step_wrench_aos(pos, quat, vel, float(fx["dt"]), quat_xyzw=True)          # array-of-structs entry
+    eng.kinetic_energy(st, rotational=True)
+    eng.step_fused_tiled(st, tiled(np.zeros_like(fx["state"])), 4096, float(fx["dt"]))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    per_body = (free0 - free1) / cap
+    print(f"engine of {cap} bodies through the tiled / AoS / fused / KE entries: {per_body:.1f} B per body of capacity")
+    assert per_body <= 80.0, per_body                                              # 68 + the test's own 4 096-body tensors
+    out_plain = eng.step_wrench(soa(fx["state"]), float(fx["dt"]), prev=soa(fx["prev"]))     # first plain-SoA call: copies are made
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert 50.0 <= (free1 - free2) / cap <= 70.0, (free1 - free2) / cap            # 44 B parameters + 14 B fp16 coefficients
+    assert np.array_equal(out_plain.cpu().numpy().T, scenes.from_tiled(w.cpu().numpy(), 4096))     # same bits through the lazy copy
+    eng.set_params(fx["params"][:4096] * np.float32(1.0), "f32")                  # a later set_params refreshes the plain copy too
+    a = eng.step_wrench(soa(fx["state"]), float(fx["dt"]), prev=soa(fx["prev"]))
+    b = eng.step_wrench_tiled(st, 4096, float(fx["dt"]), prev=pv)
+    torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy().T, scenes.from_tiled(b.cpu().numpy(), 4096))
     eng.close()
 
 
@@ -408,9 +502,17 @@ def test_yaw_equivariance_on_device(native_built):
     st[:, 5] = d * z + a * y - b * x + cc * w; st[:, 6] = d * w - a * x - b * y - cc * z
     f0, t0 = run_ext(sc.state, sc.prev, sc.params, sc.rho, sc.g, sc.dt)
     f1, t1 = run_ext(st.astype(np.float32), pv.astype(np.float32), sc.params, sc.rho, sc.g, sc.dt)
-    # rotated inputs are re-rounded to fp32, so compare with the oracle's metric at a loose gate
+    # The rotated inputs are re-rounded to fp32 (6e-8 relative per input), so this is a conditioning statement, not a
+    # rounding one: the kernel's own error is ~1e-7 (its fp64 body), what is left is the model's sensitivity to 6e-8
+    # input perturbations.  The oracle sees the same thing on the same rounded inputs - compare with IT at the parity
+    # gate, and report the equivariance residual itself.
     err = ho.wrench_error(f1, t1, f0.astype(np.float64) @ rz.T, t0.astype(np.float64) @ rz.T, sc.params, sc.rho, sc.g)
-    assert np.percentile(err, 99) < 2e-4
+    rf, rt, _ = ho.step_wrench(st.astype(np.float32), pv.astype(np.float32), sc.params, sc.rho, sc.g, sc.dt)
+    err_or = ho.wrench_error(f1, t1, rf, rt, sc.params, sc.rho, sc.g)
+    print(f"[yaw] equivariance residual p50 {np.median(err):.2e} p99 {np.percentile(err, 99):.2e} max {err.max():.2e}; "
+          f"vs the oracle on the rotated inputs: max {err_or.max():.2e}")
+    assert err_or.max() <= 5e-7                       # kernel vs oracle on the SAME (rotated, re-rounded) inputs: the parity bound
+    assert np.percentile(err, 99) < 2e-5 and np.median(err) < 5e-7     # what re-rounding the inputs costs (was 2e-4)
 
 
 # ---------------- tiled struct-of-arrays: the engine's native layout -----------------------

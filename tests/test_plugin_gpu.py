@@ -34,7 +34,7 @@ def oracle_wrench(world, prims, host, prev6, dt, semantics="numba"):
     return f, t, params
 
 
-@pytest.mark.parametrize("batched", [True, False])
+@pytest.mark.parametrize("batched", [True, "callbacks", False])
 def test_lifecycle_and_wrench_parity(batched, native_built):
     hb.REGISTRY.clear()
     world, host, prims, behaviors = build_scene(batched)
@@ -57,13 +57,19 @@ def test_lifecycle_and_wrench_parity(batched, native_built):
         assert err.max() <= 1e-5, (step, err.max())
         prev = world.velocities.cpu().numpy().copy()
         world.velocities += 0.01 * torch.randn_like(world.velocities)          # "PhysX" moves the bodies
-    # N per-prim callbacks -> one batched launch + one apply call per step (or N in per-prim mode)
+    # N prims -> one batched launch + one apply call per step (or N in per-prim mode) ...
     assert world.apply_calls == (3 if batched else 3 * n)
     if batched:
         assert len(host.views) == 1 and len(host.views[0].paths) == n
+    # ... and, in scene mode, ONE physics-step subscription for the whole group: host work per step is O(1) in prims
+    # (the reference subscribes once per prim, :131-132, as "callbacks" mode and per-prim mode do)
+    assert len(host._subs) == (1 if batched is True else n)
+    assert host.callbacks_fired == (3 if batched is True else 3 * n)
     for b in behaviors:
         b.on_stop()
-    assert not hb.REGISTRY._groups
+    assert not hb.REGISTRY._groups and not host._subs          # every subscription released (:240-245)
+    host.step(dt)                                              # nothing fires, nothing is applied after on_stop
+    assert world.apply_calls == (3 if batched else 3 * n)
     for b in behaviors:
         b.on_destroy()
     assert not prims[0].has(cfg.full_attr_name("gravity"))
@@ -286,3 +292,140 @@ def test_prepared_aos_step_and_view_pointer_changes(native_built):
         e.close()
     with pytest.raises(Exception):
         step(dt)                                                   # the engine behind a prepared call is gone
+
+
+def test_every_mode_gives_the_same_bits(native_built):
+    """Scene-level subscription, per-prim callbacks and per-prim engines apply bit-identical wrenches."""
+    got = {}
+    for mode in (True, "callbacks", False):
+        hb.REGISTRY.clear()
+        world, host, prims, behaviors = build_scene(mode, seed=11)
+        for b in behaviors:
+            b.on_play()
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        for _ in range(4):
+            host.step(1 / 60)
+            world.velocities += (0.01 * torch.randn(world.velocities.shape, generator=gen)).to(world.device)
+        torch.cuda.synchronize()
+        got[mode] = (torch.stack([world.applied[p.path][0] for p in prims]).cpu(), torch.stack([world.applied[p.path][1] for p in prims]).cpu())
+        for b in behaviors:
+            b.on_stop()
+    for mode in ("callbacks", False):
+        assert torch.equal(got[True][0], got[mode][0]) and torch.equal(got[True][1], got[mode][1]), mode
+    hb.REGISTRY.clear()
+
+
+def test_lifecycle_mirrors_the_kit_calls_of_the_reference(native_built):
+    """on_init: SimulationContext(backend="torch") first (:50-51), exposed variables (:68), then the Property-window
+    rebuild (:70); on_destroy: variables removed, rebuild again (:124-126)."""
+    hb.REGISTRY.clear()
+    world = FakeWorld("cuda:0"); host = FakeHost(world)
+    prim = cfg.AttributeStore("Femur_2"); world.add_body(prim.path, (0, 0, -5), (1, 0, 0, 0), [0] * 6, 0.75)
+    b = hb.HydrodynamicsBehavior(prim, host); b.on_init()
+    assert host.lifecycle == ["simulation_context(torch)", "create_exposed_variables", "request_rebuild"]
+    assert b._sim_context is host
+    b.on_play(); host.step(1 / 60); b.on_stop(); b.on_destroy()
+    assert host.lifecycle[3:] == ["remove_exposed_variables", "request_rebuild"]
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_engine_errors_surface_instead_of_skipping_the_step(batched, native_built, caplog):
+    """Only the state FETCH is guarded (hydrodynamics_behavior.py:177-192).  An engine error - here a view tensor the
+    C ABI refuses (not 16-byte aligned), then a closed engine - propagates out of the physics-step callback; it is not
+    swallowed as "skip this step" (HydroError is a RuntimeError, and RuntimeError is one of the guarded fetch errors)."""
+    from silver2_isaacsim_amd.engine import HydroError
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors = build_scene(batched)
+    for b in behaviors:
+        b.on_play()
+    host.step(1 / 60)
+    calls = world.apply_calls
+    view = host.views[0]
+    n = len(view.paths)
+    base = torch.empty(n * 3 + 1, device=world.device)
+    view._pos = base[1:].view(n, 3)                       # contiguous float32 on the device, but 4 bytes off alignment
+    with caplog.at_level("ERROR", logger="silver2_isaacsim_amd"):
+        with pytest.raises(HydroError, match="16-byte aligned"):
+            host.step(1 / 60)
+    assert world.apply_calls == calls                      # nothing applied for the failed step ...
+    if batched:
+        assert sum("refused the step" in r.message for r in caplog.records) == 1
+    view._pos = torch.empty((n, 3), device=world.device)
+    host.step(1 / 60)                                      # ... and the plugin works again once the input is sane
+    assert world.apply_calls == calls + 1
+    (behaviors[0]._group.engine if batched else behaviors[0]._engine).close()
+    with pytest.raises(HydroError, match="closed"):
+        host.step(1 / 60)
+    hb.REGISTRY.clear()
+
+
+@pytest.mark.parametrize("buffers", ["fresh", "strided", "numpy"])
+def test_views_that_do_not_hand_out_stable_torch_buffers(buffers, native_built, caplog):
+    """Nothing pins `get_world_poses(clone=False)` to the same contiguous device tensors every step
+    (hydrodynamics_behavior.py:178-194).  Fresh tensors per step, non-contiguous views and - a view created without the
+    torch backend - NumPy arrays all give the oracle's wrench; NumPy input is announced ONCE, never skipped silently."""
+    hb.REGISTRY.clear()
+    hb._warned_non_torch = False
+    world, host, prims, behaviors = build_main_scene(True, None, 3, view_buffers=buffers)
+    for b in behaviors:
+        b.on_play()
+    dt = 1.0 / 60.0
+    prev = np.zeros((len(prims), 6), np.float32)
+    with caplog.at_level("WARNING", logger="silver2_isaacsim_amd"):
+        for step in range(4):
+            host.step(dt)
+            torch.cuda.synchronize()
+            f_ref, t_ref, params = oracle_wrench(world, prims, host, prev, dt)
+            got_f = np.stack([world.applied[p.path][0].cpu().numpy() for p in prims])
+            got_t = np.stack([world.applied[p.path][1].cpu().numpy() for p in prims])
+            assert ho.wrench_error(got_f, got_t, f_ref, t_ref, params, 1025.0, 9.81).max() <= 1e-5, step
+            prev = world.velocities.cpu().numpy().copy()
+            world.velocities += 0.01 * torch.randn_like(world.velocities)
+    assert world.apply_calls == 4
+    stepper = behaviors[0]._group._stepper
+    assert stepper.prepared == 4 and stepper._key is None          # re-prepared every step, nothing cached
+    warned = [r for r in caplog.records if "not torch tensors" in r.message]
+    assert len(warned) == (1 if buffers == "numpy" else 0)
+    for b in behaviors:
+        b.on_stop()
+    hb.REGISTRY.clear()
+
+
+def test_config3_through_the_plugin_at_full_scale(native_built):
+    """BASELINE config 3 through `HydrodynamicsBehavior`: 19 456 prims, each with its own behavior instance, ONE
+    physics-step subscription and ONE launch per step; host time per step stays under 100 us (it does not depend on
+    the number of prims), and the applied wrench has the bits of the engine's own array-of-structs entry."""
+    import time
+    from silver2_isaacsim_amd.engine import HydroEngine
+    from silver2_isaacsim_amd.testing import build_c3_scene
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors, sc = build_c3_scene(1024)
+    assert len(prims) == 19456
+    for b in behaviors:
+        b.on_play()
+    assert len(host._subs) == 1
+    dt = sc.dt
+    # step 1 against the engine driven directly with the same tensors (previous velocity 0 on the first step, :196-198)
+    eng = HydroEngine(sc.n, "cuda:0", sc.rho, sc.g); eng.set_params(sc.params)
+    F, T = eng.step_wrench_aos(world.positions.clone(), world.orientations.clone(), world.velocities.clone(), dt)
+    host.step(dt)
+    torch.cuda.synchronize()
+    view = host.views[0]
+    assert torch.equal(view._force, F) and torch.equal(view._torque, T)
+    eng.close()
+    for _ in range(200):
+        host.step(dt)
+    torch.cuda.synchronize()
+    per_step = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(400):
+            host.step(dt)
+        torch.cuda.synchronize()
+        per_step.append((time.perf_counter() - t0) / 400 * 1e6)
+    print(f"plugin, 19 456 prims, scene mode: {sorted(per_step)[2]:.1f} us of host time per physics step (runs: {per_step})")
+    assert sorted(per_step)[2] < 100.0
+    assert host.callbacks_fired == 1 + 200 + 2000 and world.apply_calls == host.callbacks_fired
+    for b in behaviors:
+        b.on_stop()
+    assert not hb.REGISTRY._groups and not host._subs
