@@ -142,6 +142,9 @@ class Replica:
                                                                                 ke_out=ke_out, rotational=True))
         self._prepared_ke[1]()
 
+    def kinetic_energy(self):
+        return self.engine.kinetic_energy(self.state, rotational=True)
+
     def wrench_rows(self, m: int) -> np.ndarray:
         """(m,6) host copy of the first m bodies' wrench."""
         if self.layout == "tiled":
@@ -172,27 +175,31 @@ def spin_up(replicas, stream, seconds: float):
 def timed_steps(replicas, steps: int, warmup: int, stream, collectives: bool = False, after_step=None):
     """W warm-up steps, then exactly K steps between barrier+synchronize pairs.  Returns
     (wall seconds max over ranks, HIP-event milliseconds on the launch stream).
-    after_step(k, replica): called inside the timed region after step k (1-based)."""
+    after_step(k, replica): called inside the timed region after step k (1-based).
+    The launch stream is made current BEFORE the region (entering torch's stream context costs the host ~10 us, which is
+    2 % of a 20-step region and none of the K steps); without a process group the barrier is a no-op and the
+    synchronize after it is skipped."""
     dev = replicas[0].state.device
+    grouped = hd._collectives_on()
     with torch.cuda.stream(stream):
         for k in range(warmup):
             replicas[k % len(replicas)].step()
-    torch.cuda.synchronize(dev)
-    hd.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
+        torch.cuda.synchronize(dev)
+        hd.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
         ev0.record(stream)
         for k in range(steps):
             replicas[k % len(replicas)].step()
             if after_step is not None:
                 after_step(k + 1, replicas[k % len(replicas)])
         ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    hd.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        if grouped:
+            hd.barrier()
+            torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
     t = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
     hd.all_reduce_max_(t)
     return float(t.item()), float(ev0.elapsed_time(ev1))
@@ -337,6 +344,12 @@ class AosReplica:
     def out(self):
         return torch.cat([self.force, self.torque], dim=1)
 
+    def wrench_rows(self, m: int) -> np.ndarray:
+        return torch.cat([self.force[:m], self.torque[:m]], dim=1).cpu().numpy()
+
+    def kinetic_energy(self):
+        return self.engine.kinetic_energy(self.engine.pack_state_aos(self.pos, self.quat, self.vel), rotational=True)
+
     def step(self):
         if self._prepared is None:
             self._prepared = self.engine.prepare_step_wrench_aos(self.pos, self.quat, self.vel, forces=self.force, torques=self.torque)
@@ -443,21 +456,20 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, k
                 mon.observe(done, stream=stream, sampled=ke_dev)
             else:
                 reps[k % 2].step()
-    with torch.cuda.stream(stream):
+    with torch.cuda.stream(stream):                             # (made current before the region: see timed_steps)
         run(warmup, False)
-    torch.cuda.synchronize(dev)
-    hd.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
+        torch.cuda.synchronize(dev)
+        hd.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
         ev0.record(stream)
         run(steps, True)
         ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    hd.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        hd.barrier()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
     tmax = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
     hd.all_reduce_max_(tmax)
     wall, ev_ms = float(tmax.item()), float(ev0.elapsed_time(ev1))
@@ -693,8 +705,9 @@ def main():
                          "block-partitioned over the GPUs (BASELINE config 4: 262 144 bodies over 8 GPUs)")
     ap.add_argument("--spinup-seconds", type=float, default=1.0,
                     help="untimed run of the step loop before the W warm-up steps (GPU clock ramp)")
-    ap.add_argument("--layout", default="tiled", choices=["tiled", "soa"],
-                    help="tiled = engine-native tiled SoA (hydro_step_wrench_tiled); soa = plain field pointers")
+    ap.add_argument("--layout", default="tiled", choices=["tiled", "soa", "aos"],
+                    help="tiled = engine-native tiled SoA (hydro_step_wrench_tiled); soa = plain field pointers; "
+                         "aos = the simulator's (N,3)/(N,4)/(N,6) tensors (hydro_step_wrench_aos, 168 B per body-step)")
     args = ap.parse_args()
 
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("HYDRO_BENCH_FORCE_GROUP") != "1":
@@ -740,7 +753,8 @@ def main():
         desc = f"{desc} [strong scaling: {n} bodies over {world} GPUs]"
     else:
         sc = build_scene(kind, n, seed=5 + rank)
-    replicas = [Replica(sc, coeff, dev, roll=r * 131071, layout=args.layout) for r in range(args.scenes)]
+    cls = AosReplica if args.layout == "aos" else Replica
+    replicas = [cls(sc, coeff, dev, roll=r * 131071, layout=args.layout) for r in range(args.scenes)]
     if args.bodies_per_lane:
         for r in replicas:
             r.engine.set_tuning(args.bodies_per_lane)
@@ -755,7 +769,7 @@ def main():
     value = body_steps / wall
     kernel_us = ev_ms * 1e3 / args.steps              # HIP events on the launch stream around the K timed steps
     step_us = wall * 1e6 / args.steps                 # the interval `value` and `ms_per_step` are computed from
-    bpb = BYTES_PER_BODY[coeff]
+    bpb = BYTES_PER_BODY[coeff] + (24 if args.layout == "aos" else 0)        # the AoS entry also updates the engine's previous velocity
     # ONE clock for `value` and `roofline.frac`: algorithmic bytes per launch / (timed interval / K).  The event figure
     # of the same K steps (always a little shorter: it leaves out the host's synchronisation at both ends) is kept as
     # `frac_contract_steps`, the median of 5 x 200 steps as `frac_median_of_5`.
@@ -764,7 +778,7 @@ def main():
 
     # the one collective of the path: global kinetic energy (every rank reduces its shard on device)
     with torch.cuda.stream(stream):
-        ke = replicas[0].engine.kinetic_energy(replicas[0].state, rotational=True)
+        ke = replicas[0].kinetic_energy()
     stream.synchronize()
     ke = ke.to(hd.collective_device(dev))
     t0 = time.perf_counter()
@@ -788,12 +802,12 @@ def main():
                        "bodies_per_gpu": sc.n, "coefficients": coeff,
                        "scene_replicas_per_gpu": args.scenes, "bytes_per_body_step": bpb,
                        "sharding": f"bodies x{world} (no data-path collective)",
-                       "layout": "tiled SoA [tile][field][64]" if args.layout == "tiled" else "plain SoA",
-                       "entry_point": "hydro_step_wrench_tiled" if args.layout == "tiled" else "hydro_step_wrench_ext"},
+                       "layout": {"tiled": "tiled SoA [tile][field][64]", "soa": "plain SoA", "aos": "array-of-structs tensors"}[args.layout],
+                       "entry_point": {"tiled": "hydro_step_wrench_tiled", "soa": "hydro_step_wrench_ext", "aos": "hydro_step_wrench_aos"}[args.layout]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-                         "kernel": "wrench_tiled_kernel" if args.layout == "tiled" else "wrench_soa_kernel",
+                         "kernel": {"tiled": "wrench_tiled_kernel", "soa": "wrench_soa_kernel", "aos": "wrench_aos_direct_kernel"}[args.layout],
                          "clock": "the timed interval of `value` (wall time between the barrier + synchronize pairs, max over "
                                   "ranks) / steps; `kernel_us` / `frac_contract_steps` = HIP events around the same steps",
                          "step_us": step_us, "kernel_us": kernel_us,
@@ -802,8 +816,8 @@ def main():
                          "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                          # what the counters say: the kernel moves 122 B per body (fp16 coefficients), not the 130
                          # algorithmic ones - frac_traffic is the honest bandwidth fraction
-                         "traffic_bytes_per_body": TRAFFIC_BYTES_PER_BODY[coeff],
-                         "frac_traffic": sc.n * TRAFFIC_BYTES_PER_BODY[coeff] / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_bytes_per_body": bpb if args.layout == "aos" else TRAFFIC_BYTES_PER_BODY[coeff],
+                         "frac_traffic": sc.n * (bpb if args.layout == "aos" else TRAFFIC_BYTES_PER_BODY[coeff]) / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "traffic_measured": "rocprofv3 --pmc passes committed under profiles/ (not re-measured in this run)",
                          **residency(sc.n, coeff, args.scenes)},
             "spinup_seconds": args.spinup_seconds,

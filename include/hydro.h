@@ -123,10 +123,12 @@ int hydro_set_prev_velocity(hydro_t *h, int64_t n, const float *const prev[HYDRO
  * hydro_step_wrench_ext  previous velocity is the caller's (e.g. last step's velocity arrays
  *                        of a ping-pong integrator): pure 144 B (fp32) / 130 B (fp16
  *                        coefficients) per body-step, nothing written but the wrench.
- * `dt` is a double, as the `delta_time` Python float the reference's callback receives
- * (hydrodynamics_behavior.py:138,200-202).  Inputs and outputs are fp32 arrays; the arithmetic in between is
- * fp64 (the type of the reference's Numba path), each result rounded to fp32 once - which is why neither the scene
- * scalars nor 1/dt may be rounded on the way in.
+ * `dt` is a double: the reference's callback receives `delta_time` as a Python float
+ * (hydrodynamics_behavior.py:138).  Inputs and outputs are fp32 arrays; the arithmetic in between is fp64 - the type
+ * of the reference's Numba path, the parity target - each result rounded to fp32 once, which is why neither the scene
+ * scalars nor 1/dt may be rounded on the way in: the finite difference is evaluated as the
+ * Numba / fp64 oracle evaluates it.  (The reference BEHAVIOUR as shipped divides fp32 torch tensors by dt and feeds
+ * its fp32 Warp calculator, :200-209; that pipeline is the unpinned HYDRO_SEM_WARP twin, not the target.)
  * `stream` is a hipStream_t; NULL is HIP's default (null) stream, as in any HIP API.  The
  * engine's private stream (used for its own copies) is available from hydro_stream(). */
 int hydro_step_wrench(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], double dt,

@@ -102,6 +102,35 @@ if os.path.isdir(os.path.join(src, "fetch4m")):
                   f"WRITE_SIZE in separate passes, FETCH x2 (gfx950; 2 x FETCH vs the known read bytes: {100.0 * (2.0 * f4 / exp4 - 1.0):+.2f}%); "
                   f"profiles/{tag}_f16_4m_kernel_stats.csv",
     }
+# every engine kernel in one run (full bench incl. extras)
+if os.path.isdir(os.path.join(src, "allkernels")):
+    shutil.copy(one("allkernels/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_allkernels_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench_allkernels.json"), os.path.join(dst, f"{tag}_bench_under_kernel_trace.json"))
+# the simulator-facing entry: hydro_step_wrench_aos, fp32 parameters
+if os.path.isdir(os.path.join(src, "aos_fetch")):
+    shutil.copy(one("aos_stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_aos_1m_kernel_stats.csv"))
+    shutil.copy(one("aos_stats4m/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_aos_4m_kernel_stats.csv"))
+
+    def med_aos(sub, counter):
+        vals = []
+        with open(one(os.path.join(sub, "**", "*counter_collection.csv")), newline="") as f:
+            for r in csv.DictReader(f):
+                if "wrench_aos" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        return statistics.median(vals) * 1024.0
+    fa, wa = med_aos("aos_fetch", "FETCH_SIZE"), med_aos("aos_write", "WRITE_SIZE")
+    ba = json.load(open(os.path.join(src, "bench_aos_stats.json"))); ba4 = json.load(open(os.path.join(src, "bench_aos_stats4m.json")))
+    na = ba["config"]["bodies_per_gpu"]
+    tr["c5-f32:aos"] = {
+        "hbm_bytes_per_launch": 2.0 * fa + wa, "fetch_size_bytes_raw": fa, "fetch_size_bytes_corrected": 2.0 * fa, "write_size_bytes": wa,
+        "expected_read_bytes": na * (12 + 16 + 24 + 24 + 44), "expected_write_bytes": na * (24 + 24), "algorithmic_bytes": na * 168,
+        "in_bench_event_us": {"under_kernel_trace_1m": ba["roofline"]["kernel_us"], "under_kernel_trace_4m": ba4["roofline"]["kernel_us"]},
+        "frac_of_8TBs": {"1m": ba["roofline"]["frac_contract_steps"], "4m": ba4["roofline"]["frac_contract_steps"]},
+        "source": f"python bench.py --layout aos --workload c5-f32 (hydro_step_wrench_aos, fp32 parameters, engine-owned previous velocity); rocprofv3 "
+                  f"--pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 (gfx950; the x2 calibration is that of the 4-byte streaming pattern; "
+                  f"2 x FETCH vs the known read bytes here: {100.0 * (2.0 * fa / (na * 120) - 1.0):+.2f}%); profiles/{tag}_aos_1m_kernel_stats.csv, {tag}_aos_4m_kernel_stats.csv",
+    }
 json.dump(tr, open(path, "w"), indent=1)
+print(json.dumps(tr.get("c5-f32:aos"), indent=1))
 print(json.dumps(tr["c5:tiled"], indent=1))
 print(json.dumps(tr.get("f16_4m:tiled"), indent=1))

@@ -21,6 +21,10 @@ big="--bodies 4194304 --scenes 2 --steps 40 --warmup 8 --spinup-seconds 0.2 --cp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats4m" -- python3 bench.py --bodies 4194304 --scenes 2 --steps 400 --warmup 40 --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic > "$out/bench_stats4m.json" 2> "$out/stats4m.err" || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch4m" -- python3 bench.py $big > "$out/bench_fetch4m.json" 2> "$out/fetch4m.err" || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write4m" -- python3 bench.py $big > "$out/bench_write4m.json" 2> "$out/write4m.err" || exit 1
+# every engine kernel in one run: the full default bench (headline + roofline_4m + all extras) under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/allkernels" -- python3 bench.py --cpu-seconds 0 --no-live-traffic > "$out/bench_allkernels.json" 2> "$out/allkernels.err" || exit 1
+find "$out/allkernels" -name "*kernel_trace.csv" -delete
+bash scripts/profile_aos.sh "$tag" || exit 1
 find "$out/stats4m" -name "*kernel_trace.csv" -size +20M -delete
 # keep the merge-back small: the per-dispatch traces of the stats run are large
 find "$out/stats" -name "*kernel_trace.csv" -size +20M -delete

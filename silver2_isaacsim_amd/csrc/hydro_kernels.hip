@@ -290,8 +290,8 @@ __device__ __forceinline__ void wave_lds_fence()
 // Coalescing is that of plain SoA (each wave-instruction still reads one 256-B run), but the
 // ~28 runs a wave needs are now 3 contiguous records (3.3 KiB state, 1.5 KiB previous velocity,
 // 2.75 KiB parameters) instead of 28 pieces scattered over 28 arrays: DRAM pages are used whole.
-// Measured (scripts/tune.py, memory-only probes, 4M bodies): 6.1 TB/s against 5.4 TB/s for
-// plain SoA, i.e. the float4-copy ceiling of the box.  All field offsets f*256 B fit the 12-bit
+// Measured with memory-only probes at 4M bodies (round 1; the probes of this shape live in scripts/probes.py now):
+// 6.1 TB/s against 5.4 TB/s for plain SoA, i.e. the float4-copy ceiling of the box.  All field offsets f*256 B fit the 12-bit
 // immediate of global_load, so a wave needs ONE 32-bit offset register per record.
 // --------------------------------------------------------------------------
 struct TiledArgs {
@@ -940,21 +940,26 @@ __global__ void __launch_bounds__(kBlock) ke_partial_kernel(const KeArgs a)
     ke_block_partial(lin, rot, a.partials, a.partial_stride);
 }
 
-// Second stage: ONE block adds the per-block partials in a fixed order (thread t takes t, t + 1024, ...; then a tree).
+// Second stage: ONE block adds the per-block partials in a fixed order: thread t takes t, t + 1024, ... (batches of
+// eight loads in flight), then the wave64 shuffle tree, then the 16 wave sums in order.  One workgroup barrier.
 __global__ void __launch_bounds__(kKeFinalBlock) ke_final_kernel(const double* __restrict__ partials, uint32_t nblocks, uint32_t stride,
                                                                  double* __restrict__ out)
 {
-    __shared__ double red[2][kKeFinalBlock];
+    __shared__ double red[2][kKeFinalBlock / 64];
     double l = 0.0, r = 0.0;
 #pragma unroll 8
     for (uint32_t k = threadIdx.x; k < nblocks; k += kKeFinalBlock) { l += partials[k]; r += partials[stride + k]; }
-    red[0][threadIdx.x] = l; red[1][threadIdx.x] = r;
+    l = wave_sum(l);
+    r = wave_sum(r);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = l; red[1][wave] = r; }
     __syncthreads();
-    for (int s = kKeFinalBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        double sl = 0.0, sr = 0.0;
+#pragma unroll
+        for (int w = 0; w < kKeFinalBlock / 64; ++w) { sl += red[0][w]; sr += red[1][w]; }
+        out[0] = sl; out[1] = sr;
     }
-    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
 }
 
 // --------------------------------------------------------------------------
@@ -1230,11 +1235,12 @@ int ensure_soa_prev(hydro_engine* h)
     return HYDRO_OK;
 }
 
-// Launch geometry, measured on MI355X (scripts/tune.py, interleaved A/B):
+// Launch geometry, measured on MI355X (interleaved A/B of whole libraries, scripts/ab_variants.py):
 //   * non-temporal accesses: +5..9 % once the scene is larger than the caches; small scenes keep
 //     temporal accesses so that a few-MB working set stays L2 / Infinity-Cache resident between steps;
-//   * 128-thread blocks: +8..12 % around 1M bodies (finer dispatch granularity shortens the ramp and
-//     the tail of a ~25 us launch), -3 % at 4M where 256 is kept.
+//   * block size: with the fp64 body 128- and 256-thread blocks of the tiled kernel measure the same at 1M bodies
+//     (+-0.1 us) and 256 is 1-2 us faster at 4M: the tiled kernel always launches 256.  (Round 1's fp32 body gained
+//     8..12 % from 128-thread blocks around 1M; the plain-SoA kernel keeps that rule below 2M bodies.)
 constexpr int64_t kNtMinBodies = 131072;
 // The fused step is the closed-loop kernel: ONE scene stepping on itself (state ping-pong + parameters,
 // ~150 B of working set per body).  Between ~0.45M and ~2.6M bodies that set fits, or mostly fits, the 256 MiB

@@ -55,10 +55,12 @@ def test_fused_wrench_matches_oracle_on_fixtures(name, vec, native_built):
 
 @pytest.mark.parametrize("dt", [1.0 / 60.0, 1.0 / 120.0, 0.004999999999999999])
 def test_dt_is_a_double_through_the_abi(dt, native_built):
-    """The reference's callback receives `delta_time` as a Python float and divides by it in float64
-    (hydrodynamics_behavior.py:138,200-202).  1/60 is not an fp32 number: rounded to fp32 it is 5e-8 off, which an
-    added-mass-dominated body shows in full.  The C ABI takes dt as a double; results follow the oracle evaluated
-    with the SAME double to fp32 rounding, and differ from those of the fp32-rounded step."""
+    """The reference's callback receives `delta_time` as a Python float (hydrodynamics_behavior.py:138); the parity
+    target - the Numba / fp64 oracle - evaluates the finite difference (v - v_last) / dt in float64.  (The shipped
+    behaviour itself divides fp32 torch tensors and feeds the fp32 Warp calculator, :200-209: the fp64 target is this
+    repository's oracle of the Numba path, not that pipeline.)  1/60 is not an fp32 number: rounded to fp32 it is 5e-8
+    off, which an added-mass-dominated body shows in full.  The C ABI takes dt as a double; results follow the oracle
+    evaluated with the SAME double to fp32 rounding, and differ from those of the fp32-rounded step."""
     sc = scenes.scene_c2()
     params = sc.params.copy()
     params[:, 8] *= 20.0; params[:, 9] *= 20.0                       # added mass dominates the wrench
@@ -210,9 +212,12 @@ def test_component_mode_matches_reference_outputs(name, native_built):
     print(f"[components {name}] per-component max {rel.max():.3e} median {np.median(rel):.3e}; centres max {cen:.3e} m (fp32 ulp there {ulp_p:.3e})")
     # the body is evaluated in fp64 and each component rounded to fp32 ONCE: half an ulp per coordinate, i.e. at most
     # sqrt(3) * 2^-24 = 1.03e-7 of the component's own norm (a bound, not an allowance; was 5e-5 for the fp32 body).
+    # On top of that this entry takes the ACCELERATIONS as fp32 arrays while the fixtures' reference outputs used the
+    # float64 finite difference: the added-mass components (linear in the acceleration) inherit that input rounding,
+    # another 1.03e-7 -> 2.1e-7 in all (measured: c2 1.09e-7, c4 1.86e-7).
     # The K vectors ("kat") are the exception: their inputs are float64 numbers (SURVEY's raw quaternions normalised in
     # fp64), so handing them to an fp32 interface rounds the INPUTS by 6e-8 and the lift follows with 5e-7.
-    assert rel.max() < (1.1e-7 if name != "kat" else 2e-6)
+    assert rel.max() < (2.1e-7 if name != "kat" else 2e-6)
     assert np.median(rel) < 6e-8
     # centres: fp64 lever arm + position, rounded once to a world-space fp32 number: half an ulp of |p|
     assert cen <= 0.5 * ulp_p * 1.0001

@@ -352,7 +352,7 @@ def test_engine_errors_surface_instead_of_skipping_the_step(batched, native_buil
         assert sum("refused the step" in r.message for r in caplog.records) == 1
     view._pos = torch.empty((n, 3), device=world.device)
     host.step(1 / 60)                                      # ... and the plugin works again once the input is sane
-    assert world.apply_calls == calls + 1
+    assert world.apply_calls == calls + (1 if batched else len(prims))
     (behaviors[0]._group.engine if batched else behaviors[0]._engine).close()
     with pytest.raises(HydroError, match="closed"):
         host.step(1 / 60)
@@ -383,7 +383,8 @@ def test_views_that_do_not_hand_out_stable_torch_buffers(buffers, native_built, 
             world.velocities += 0.01 * torch.randn_like(world.velocities)
     assert world.apply_calls == 4
     stepper = behaviors[0]._group._stepper
-    assert stepper.prepared == 4 and stepper._key is None          # re-prepared every step, nothing cached
+    assert stepper.prepared == 4                                   # re-prepared every step: new buffers, new launch arguments
+    assert buffers == "fresh" or stepper._key is None              # converted copies are never remembered
     warned = [r for r in caplog.records if "not torch tensors" in r.message]
     assert len(warned) == (1 if buffers == "numpy" else 0)
     for b in behaviors:
@@ -406,7 +407,11 @@ def test_config3_through_the_plugin_at_full_scale(native_built):
     assert len(host._subs) == 1
     dt = sc.dt
     # step 1 against the engine driven directly with the same tensors (previous velocity 0 on the first step, :196-198)
-    eng = HydroEngine(sc.n, "cuda:0", sc.rho, sc.g); eng.set_params(sc.params)
+    # (the plugin reads water density and gravity back from Float - 32-bit - USD attributes, as the reference does:
+    # its g is float32(9.81) = 9.8100004196167, and the engine driven directly has to use the same number)
+    grp = behaviors[0]._group
+    assert (grp.rho, grp.g) == (1025.0, float(np.float32(9.81)))
+    eng = HydroEngine(sc.n, "cuda:0", grp.rho, grp.g); eng.set_params(sc.params)
     F, T = eng.step_wrench_aos(world.positions.clone(), world.orientations.clone(), world.velocities.clone(), dt)
     host.step(dt)
     torch.cuda.synchronize()

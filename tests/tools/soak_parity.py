@@ -17,13 +17,24 @@ threads = min(64, c_oracle.max_threads())
 edges = [0, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 1e-3, 1e9]
 total = {"bodies": 0, "hist": [0] * (len(edges) - 1), "max": 0.0, "worst": None}
 per = []
+ke_checks = [0]
 
 def run(sc, coeff, entry):
     eng = HydroEngine(sc.n, dev, sc.rho, sc.g); eng.set_params(sc.params, coeff)
     if entry == "tiled":
+        # (through the variant that also samples the kinetic energy in-kernel: same wrench bits, and the pair is checked
+        # against the fp64 host sum)
+        ke = torch.zeros(2, dtype=torch.float64, device=dev)
         out = eng.step_wrench_tiled(torch.from_numpy(scenes.to_tiled(sc.state)).to(dev), sc.n, sc.dt,
-                                    prev=torch.from_numpy(scenes.to_tiled(sc.prev)).to(dev))
+                                    prev=torch.from_numpy(scenes.to_tiled(sc.prev)).to(dev), ke_out=ke)
         o = scenes.from_tiled(out.cpu().numpy(), sc.n)
+        prm = sc.params.copy()
+        if coeff == "f16":
+            prm[:, 3:10] = prm[:, 3:10].astype(np.float16).astype(np.float32)
+        want = ho.kinetic_energy(sc.state, prm, True)[0]
+        got = float(ke.sum().item())
+        assert abs(got - want) <= 1e-12 * abs(want), ("kinetic energy sampled in the step kernel", got, want)
+        ke_checks[0] += 1
     elif entry == "soa":
         out = eng.step_wrench(torch.from_numpy(scenes.to_soa(sc.state)).to(dev), sc.dt, prev=torch.from_numpy(scenes.to_soa(sc.prev)).to(dev))
         o = out.cpu().numpy().T
@@ -72,6 +83,7 @@ summ = {"bodies_checked": total["bodies"], "bin_edges": edges[:-1] + ["inf"], "h
         "worst_case": total["worst"], "bodies_over_1e-5_gated": sum(r["over_1e-5"] for r in per if r["gated"]),
         "bodies_gated": sum(r["n"] for r in per if r["gated"]), "bodies_over_1e-5_ungated": sum(r["over_1e-5"] for r in per if not r["gated"]),
         "bodies_ungated": sum(r["n"] for r in per if not r["gated"]), "metric": "SURVEY.md 8d per-body wrench error vs fp64 C oracle",
+        "kinetic_energy_samples_checked_vs_fp64_host_sum_1e-12": ke_checks[0],
         "runs": per}
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 json.dump(summ, open(os.path.join(REPO, "gpurun_out", os.environ.get("HYDRO_SOAK_OUT", "parity_soak.json")), "w"), indent=1)
