@@ -7,6 +7,12 @@ per HIP-graph replay.  Prints the real-time factor the way the reference's bench
 and the global kinetic energy before / after (the drag has to dissipate it).
 
     python examples/silver2_envs_headless.py --envs 1024 --steps 2048
+    python examples/silver2_envs_headless.py --envs 1024 --steps 2048 --through-plugin
+
+`--through-plugin` drives the same 19 x envs bodies through the PLUGIN surface instead: one `HydrodynamicsBehavior`
+instance per prim on the in-memory host (silver2_isaacsim_amd.testing), one physics-step subscription for the group,
+one hydro_step_wrench_aos launch and one apply per step; the bodies do not move (the host has no PhysX), what is
+reported is the host time per physics step and the real-time factor it allows.
 """
 import argparse
 import json
@@ -24,7 +30,10 @@ def main(argv=None):
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--through-plugin", action="store_true")
     args = ap.parse_args(argv)
+    if args.through_plugin:
+        return through_plugin(args)
     sc = scenes.scene_c3(envs=args.envs)
     sim = ClosedLoopSim(sc, device=args.device, fused=True, implicit_drag=True)
     ke0 = sim.kinetic_energy(rotational=True)
@@ -35,6 +44,33 @@ def main(argv=None):
            "kinetic_energy_J": {"before": [float(x) for x in ke0], "after": [float(x) for x in ke1]},
            "finite": bool((state == state).all()), "deepest_z": float(state[:, 2].min()), "highest_z": float(state[:, 2].max())}
     sim.close()
+    print(json.dumps(out))
+    return out
+
+
+def through_plugin(args):
+    import time
+    import torch
+    from silver2_isaacsim_amd import behavior as hb
+    from silver2_isaacsim_amd.testing import build_c3_scene
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors, sc = build_c3_scene(args.envs, device=args.device)
+    for b in behaviors:
+        b.on_play()
+    for _ in range(100):
+        host.step(sc.dt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        host.step(sc.dt)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out = {"bodies": len(prims), "envs": args.envs, "dt": sc.dt, "mode": "HydrodynamicsBehavior x %d on the in-memory host" % len(prims),
+           "physics_steps": args.steps, "wall_time_s": wall, "us_per_physics_step": wall / args.steps * 1e6,
+           "rtf": args.steps * sc.dt / wall, "physics_step_subscriptions": len(host._subs), "apply_calls": world.apply_calls}
+    for b in behaviors:
+        b.on_stop()
+    hb.REGISTRY.clear()
     print(json.dumps(out))
     return out
 

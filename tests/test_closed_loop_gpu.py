@@ -129,6 +129,10 @@ def test_silver2_envs_example(native_built):
     assert out["rtf"] > 10.0                                            # 120 Hz scene, microseconds per step
     ke0, ke1 = out["kinetic_energy_J"]["before"], out["kinetic_energy_J"]["after"]
     assert ke1[1] < ke0[1]                                              # the angular drag dissipates the initial spin
+    # the same bodies through the plugin surface: one behavior instance per prim, one subscription, one launch per step
+    via = demo.main(["--envs", "64", "--steps", "200", "--through-plugin"])
+    assert via["bodies"] == 19 * 64 and via["physics_step_subscriptions"] == 1 and via["apply_calls"] == 300
+    assert via["rtf"] > 10.0
 
 
 def test_checkpoint_resume_is_bit_exact(native_built):
