@@ -128,6 +128,75 @@ __global__ void __launch_bounds__(256) probe_compute(const PArgs a, double rho, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// clock probes: the shader clock each kind of work holds (DVFS: MI355X_MICROARCH.md "DVFS give-back").  Every wave
+// stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its body and lane 0 leaves the two differences
+// in a buffer nothing else reads; clock = d(memtime) / d(memrealtime) x 100 MHz, median over the waves of a launch.
+//   KIND 0: the product kernel's whole body (28 loads from ITS tile, solve_wrench, 6 stores) - what the tiled wrench
+//           kernel does, stamped;   KIND 1: memory only (loads, trivial combine, 6 stores);   KIND 2: compute only
+//           (L2-resident inputs, one store).
+// ---------------------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(256) probe_clock(const PArgs a, uint64_t* __restrict__ stamps, double rho, double g, double inv_dt)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (tile >= a.tiles) return;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t lt = KIND == 2 ? (tile & 63u) : tile;
+    const float* s = a.st + (size_t)lt * 832 + lane; const float* p = a.pv + (size_t)lt * 384 + lane;
+    const float* q = a.prm + (size_t)lt * 480 + lane;
+    const unsigned short* hq = reinterpret_cast<const unsigned short*>(a.prm + (size_t)lt * 480 + 256) + lane;
+    float* o = a.out + (size_t)tile * 384 + lane;
+    if constexpr (KIND == 1) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int f = 2; f < 13; ++f) acc += ldnt(s + f * 64);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) acc += ldnt(p + f * 64);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc += ldnt(q + f * 64);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) acc += (float)ldnt(hq + f * 64);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) stnt(o + f * 64, acc + (float)f);
+    } else {
+        hydro::BodyIn b;
+        float pv[6], mass;
+        b.px = 0.0f; b.py = 0.0f; b.pz = ldnt(s + 2 * 64);
+        b.qx = ldnt(s + 3 * 64); b.qy = ldnt(s + 4 * 64); b.qz = ldnt(s + 5 * 64); b.qw = ldnt(s + 6 * 64);
+        b.vx = ldnt(s + 7 * 64); b.vy = ldnt(s + 8 * 64); b.vz = ldnt(s + 9 * 64);
+        b.wx = ldnt(s + 10 * 64); b.wy = ldnt(s + 11 * 64); b.wz = ldnt(s + 12 * 64);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) pv[f] = ldnt(p + f * 64);
+        b.dimx = ldnt(q); b.dimy = ldnt(q + 64); b.dimz = ldnt(q + 128); mass = ldnt(q + 192);
+        b.cd_lin = h2f(ldnt(hq)); b.cd_ang = h2f(ldnt(hq + 64)); b.damp_lin = h2f(ldnt(hq + 128)); b.damp_ang = h2f(ldnt(hq + 192));
+        b.lift = h2f(ldnt(hq + 256)); b.am_lin = h2f(ldnt(hq + 320)); b.am_ang = h2f(ldnt(hq + 384));
+        const hydro::Wrench w = hydro::solve_wrench(b, pv, mass, rho, g, inv_dt, false);
+        if constexpr (KIND == 0) {
+            stnt(o, w.fx); stnt(o + 64, w.fy); stnt(o + 128, w.fz); stnt(o + 192, w.tx); stnt(o + 256, w.ty); stnt(o + 320, w.tz);
+        } else {
+            stnt(a.out + (size_t)tile * 64 + lane, ((w.fx + w.fy) + (w.fz + w.tx)) + (w.ty + w.tz));
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                                  // the stores have left before the closing stamp
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { stamps[2 * tile] = t1 - t0; stamps[2 * tile + 1] = r1 - r0; }
+}
+
+extern "C" int probe_launch_clock(int kind, const PArgs* a, void* stamps, void* stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((a->tiles * 64 + 255) / 256), blk(256);
+    uint64_t* st = static_cast<uint64_t*>(stamps);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(probe_clock<0>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
+        case 1: hipLaunchKernelGGL(probe_clock<1>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
+        case 2: hipLaunchKernelGGL(probe_clock<2>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // memory-only probe of the array-of-structs entry (hydro_step_wrench_aos, fp32 parameters): 168 B per body =
 // positions 12 + orientations 16 + velocities 24 + previous velocity 24 read and 24 written + parameters 44 in,
 // forces 12 + torques 12 out.  WIDE: the simulator tensors as whole 16-byte chunks per wave (what the LDS-staged

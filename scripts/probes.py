@@ -152,6 +152,52 @@ def bound_probes(n: int, dev, stream, rounds: int = 5, which=(0, 4, 5), with_aos
     return out
 
 
+def clock_probes(n: int, dev, stream, seconds: float = 2.0) -> dict:
+    """The shader clock the chip holds under each kind of work (DVFS), read in-kernel: every wave stamps s_memtime /
+    s_memrealtime around its body.  Each kind is run back to back for `seconds` first (the clock needs that long to
+    settle), then 50 stamped launches are evaluated: median over waves and launches of cycles / real time.
+    Returns {kind: {"ghz", "wave_lifetime_us", "us_per_launch"}} for the whole body (what the tiled wrench kernel does),
+    memory only, compute only."""
+    import time
+    import bench
+    L = lib()
+    L.probe_launch_clock.argtypes = [ctypes.c_int, ctypes.POINTER(PArgs), ctypes.c_void_p, ctypes.c_void_p]
+    sets = 4 if n <= 1048576 else 2
+    sc = bench.build_scene("c5", n, 5)
+    tiles = n // 64
+    from silver2_isaacsim_amd import scenes
+    bufs = _tiled_buffers(n, sets, dev, real_scene=None)
+    # real bodies everywhere: the whole-body probe must do the product's arithmetic on the product's data
+    st = torch.from_numpy(scenes.to_tiled(sc.state).reshape(-1)).to(dev); pv = torch.from_numpy(scenes.to_tiled(sc.prev).reshape(-1)).to(dev)
+    prm = torch.from_numpy(_f16_param_records(sc.params).reshape(-1)).to(dev)
+    for b in bufs:
+        b[0][:st.numel()] = st; b[1][:pv.numel()] = pv; b[2][:prm.numel()] = prm
+    stamps = torch.zeros(2 * tiles, dtype=torch.int64, device=dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    out = {}
+    with torch.cuda.stream(stream):
+        for kind, name in ((0, "whole_body"), (1, "memory_only"), (2, "compute_only")):
+            t0 = time.perf_counter(); r = 0
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(64):
+                    L.probe_launch_clock(kind, ctypes.byref(bufs[r % sets][4]), stamps.data_ptr(), sp); r += 1
+                stream.synchronize()
+            ghz, life = [], []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for k in range(50):
+                L.probe_launch_clock(kind, ctypes.byref(bufs[k % sets][4]), stamps.data_ptr(), sp)
+                if k % 10 == 9:                          # (reading the stamps back drains the queue: every tenth launch only)
+                    stream.synchronize()
+                    v = stamps.view(tiles, 2).double()
+                    ok = v[:, 1] > 0
+                    ghz.append(float((v[ok, 0] / v[ok, 1]).median()) * 0.1)
+                    life.append(float(v[ok, 1].median()) * 0.01)
+            e1.record(stream); stream.synchronize()
+            out[name] = {"ghz": statistics.median(ghz), "wave_lifetime_us": statistics.median(life)}
+    return out
+
+
 def _aos_case(sc, n, sets, dev, L, sp):
     """The array-of-structs entry (fp32 parameters, engine-owned previous velocity) beside memory-only probes of its
     168 B/body in both access shapes."""
@@ -189,6 +235,12 @@ if __name__ == "__main__":
         r = bound_probes(n, dev, stream, rounds=7, which=(0, 1, 2, 4, 5))
         for name, us in r["us"].items():
             line = f"n={n:9d} {name:58s}: {us:8.2f} us"
+            print(line, flush=True); log.write(line + "\n")
+        log.flush()
+        torch.cuda.empty_cache()
+        c = clock_probes(n, dev, stream)
+        for name, v in c.items():
+            line = f"n={n:9d} clock held under {name:13s}: {v['ghz']:.3f} GHz   (median wave lifetime {v['wave_lifetime_us']:.2f} us)"
             print(line, flush=True); log.write(line + "\n")
         log.flush()
         torch.cuda.empty_cache()

@@ -434,3 +434,50 @@ def test_config3_through_the_plugin_at_full_scale(native_built):
     for b in behaviors:
         b.on_stop()
     assert not hb.REGISTRY._groups and not host._subs
+
+
+@pytest.mark.parametrize("mode", [True, "callbacks"])
+def test_membership_changes_between_steps(mode, native_built):
+    """Prims stop and play again while the others keep stepping: the batch is rebuilt with the members of the moment
+    (no stale or duplicate rows), each member's wrench is the oracle's for ITS state - members that stay keep their own
+    previous-step velocity across the rebuild, as the reference's per-prim `_last_*_velocity` do (:196-198,237-238), a prim
+    that comes back starts from zero - and the subscription count follows."""
+    hb.REGISTRY.clear()
+    world, host, prims, behaviors = build_scene(mode, seed=7)
+    for b in behaviors:
+        b.on_play()
+    dt = 1.0 / 60.0
+    host.step(dt); torch.cuda.synchronize()
+    prev = world.velocities.cpu().numpy().copy()
+    gone = [3, 9, 17]
+    for k in gone:
+        behaviors[k].on_stop()
+    assert len(host._subs) == (1 if mode is True else len(prims) - len(gone))
+
+    def check(active, prev_rows):
+        f_ref, t_ref, params = oracle_wrench(world, prims, host, prev_rows, dt)
+        got_f = np.stack([world.applied[prims[k].path][0].cpu().numpy() for k in active])
+        got_t = np.stack([world.applied[prims[k].path][1].cpu().numpy() for k in active])
+        err = ho.wrench_error(got_f, got_t, f_ref[active], t_ref[active], params[active], 1025.0, 9.81)
+        assert err.max() <= 1e-5, err.max()
+    active = [k for k in range(len(prims)) if k not in gone]
+    world.velocities += 0.01 * torch.randn_like(world.velocities)
+    host.step(dt); torch.cuda.synchronize()
+    assert len(host.views[-1].paths) == len(active)
+    if mode is True or mode == "callbacks":
+        check(active, prev)                                           # the batch was rebuilt; nobody's finite difference was reset
+    prev = world.velocities.cpu().numpy().copy()
+    behaviors[9].on_play()                                           # one comes back
+    active = sorted(active + [9])
+    world.velocities += 0.01 * torch.randn_like(world.velocities)
+    host.step(dt); torch.cuda.synchronize()
+    assert len(host.views[-1].paths) == len(active) and len(set(host.views[-1].paths)) == len(active)
+    prev[9] = 0.0                                                     # ... except the newcomer's: it starts from zero
+    check(active, prev)
+    prev = world.velocities.cpu().numpy().copy()
+    world.velocities += 0.01 * torch.randn_like(world.velocities)
+    host.step(dt); torch.cuda.synchronize()
+    check(active, prev)                                               # ... and from then on the finite difference
+    for b in behaviors:
+        b.on_stop()
+    assert not hb.REGISTRY._groups and not host._subs
