@@ -64,7 +64,7 @@ constexpr double kClampEps = 1e-6;      // hydrodynamics_behavior.py:224
 // in fp64, which squares the error: 1.4e-14 relative - five orders of magnitude below the fp32 rounding of the results,
 // so even a 1e5-fold cancellation downstream stays at 1e-9.  5 and 7 instructions where the IEEE-exact sequences the
 // compiler expands `/` and sqrt() to take ~15 and ~25.  Arguments are within fp32 range wherever the result is used
-// (guarded by the model's own 1e-6 thresholds); sqrt64 returns 0 below 1e-30.  Plain libm on the host instantiation.
+// (guarded by the model's own 1e-6 thresholds).  Plain libm on the host instantiation.
 HYDRO_FN double rcp64(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -74,14 +74,28 @@ HYDRO_FN double rcp64(double x)
     return 1.0 / x;
 #endif
 }
+// Both take the seed of max(x, 1e-36): x = 0 then gives exactly 0 (0 times a finite seed) with no compare-and-select, and
+// nothing below 1e-36 is ever meaningful here (squared speeds under the model's 1e-12, products of O(1) geometry).
 HYDRO_FN double sqrt64(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double r = (double)__builtin_amdgcn_rsqf((float)x);
+    const double r = (double)__builtin_amdgcn_rsqf(__builtin_fmaxf((float)x, 1e-36f));
     const double y = x * r;
-    return x > 1e-30 ? __builtin_fma(__builtin_fma(-y, y, x), 0.5 * r, y) : 0.0;
+    return __builtin_fma(__builtin_fma(-y, y, x), 0.5 * r, y);
 #else
-    return x > 1e-30 ? sqrt(x) : 0.0;
+    return x > 0.0 ? sqrt(x) : 0.0;
+#endif
+}
+// 1 / sqrt(x): the same seed, one Newton step on the inverse root (error (3/8) e^2 ~ 2e-14).  x * rsqrt64(x) is sqrt(x)
+// to the same accuracy, so a quantity and its inverse (|v| and 1 / |v|) cost ONE seed and nine instructions.
+HYDRO_FN double rsqrt64(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = (double)__builtin_amdgcn_rsqf(__builtin_fmaxf((float)x, 1e-36f));
+    const double e = __builtin_fma(-(x * r), r, 1.0);
+    return __builtin_fma(0.5 * r, e, r);
+#else
+    return 1.0 / sqrt(x > 1e-36 ? x : 1e-36);
 #endif
 }
 
@@ -100,6 +114,19 @@ HYDRO_FN float fast_rcp(float x)
     return __builtin_amdgcn_rcpf(x);
 #else
     return 1.0f / x;
+#endif
+}
+
+// a * b with 0 * anything = +0 (also 0 * inf, 0 * NaN): v_mul_legacy_f32.  One instruction zeroes a dry body's outputs
+// through the factor they are multiplied by anyway, whatever their value.
+HYDRO_FN float mul_zero_wins(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;                                            // (no builtin for it on gfx950; the instruction is there)
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (a == 0.0f || b == 0.0f) ? 0.0f : a * b;
 #endif
 }
 
@@ -155,18 +182,20 @@ struct Body {
     bool wet;                       // ratio > 1e-9; the zeros of a dry body (A4) are applied by assemble_wrench / round_components
 };
 
-// A1-A11 for one body.  (ax..bz) = linear / angular acceleration.  rho, g: scene scalars
+// A1-A11 for one body.  (ax..bz) * acc_scale = linear / angular acceleration: the fused entries pass the velocity
+// DIFFERENCES and 1/dt (the finite difference of hydrodynamics_behavior.py:200-202; the scale is folded into the two
+// added-mass factors instead of six products), component mode passes accelerations and 1.  rho, g: scene scalars
 // (hydrodynamics_config.json:2-5 "globals"), doubles as the reference passes Python floats.
 // `warp` (uniform over a launch) selects the semantics of the reference's Warp twin where it differs from the Numba
 // path (include/hydro.h HYDRO_SEM_WARP - PARITY UNPINNED for that mode); the default is Numba.
 //
-// `late(anchor, ...)` supplies what only the LAST block (A10, added mass) consumes: the six accelerations and the two
-// added-mass coefficients.  It is called right where they are needed, with a value computed in the middle of the body
-// (`anchor`): a kernel may tie its loads of those inputs to it so that they are issued late and their registers are
-// not live through the first two thirds of the arithmetic (hydro_kernels.hip, LATE template argument).  The results
-// do not depend on where the inputs come from.
-template <class Late>
-HYDRO_FN Body solve_body_with(const BodyIn& b, Late&& late, double rho, double g, bool warp)
+// Instruction count matters as much as bytes here: under the combined load of this kernel the chip holds ~2.0 GHz
+// (2.4 for its memory traffic or its arithmetic alone) and at that clock the ~500 VALU instructions of a body take as
+// long as its 122 bytes.  Hence the forms below: selects that the arithmetic already implies are
+// not written (a face with u_a = 0 has area 0 by itself; a full body's ratio clamps to 1 by itself; ...), |v| and 1/|v|
+// share one seed, min() instead of compare-and-select.  Each such form is exact or moves a result by < 1e-13.
+HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, double bx, double by, double bz, double acc_scale,
+                         double rho, double g, bool warp = false)
 {
     Body o;
     // ---- A1: rotation matrix (numba_hydrodynamics.py:14-49), the quaternion used as given (N7) ----
@@ -186,12 +215,12 @@ HYDRO_FN Body solve_body_with(const BodyIn& b, Late&& late, double rho, double g
     const double extent = fabs(ex) + fabs(ey) + fabs(ez);
     const double pz = (double)b.pz + 0.0;               // -0.0 -> +0.0: no keypoint height below can then be -0.0
     const double zlo = pz - extent, zhi = pz + extent;  // lowest / highest keypoint
-    const bool dry = zlo >= 0.0, full = zhi <= 0.0;
     const double height = zhi - zlo;
+    // ratio = 0 if z_lo >= 0, 1 if z_hi <= 0, else min(1, -z_lo / height) (1 for a degenerate height).  Written as ONE
+    // clamp: z_hi <= 0 makes -z_lo >= height, so the quotient is >= 1 by itself, and z_lo >= 0 makes it <= 0 - which
+    // `wet` below reads as dry (every output of a dry body is selected to zero at the end, A4).
     double ratio = fmin(1.0, -zlo * rcp64(height));
-    if (height < kHeightEps) ratio = 1.0;               // z_lo < 0 is known here
-    if (full) ratio = 1.0;
-    if (dry) ratio = 0.0;
+    if (height < kHeightEps) ratio = (zlo < 0.0) ? 1.0 : 0.0;
     o.ratio = ratio;
     o.wet = ratio > kDryEps;                            // A4 (:277-279)
 
@@ -215,82 +244,91 @@ HYDRO_FN Body solve_body_with(const BodyIn& b, Late&& late, double rho, double g
     const int s_i = __builtin_popcount(wetmask & lattice_mask(0, 2)) - __builtin_popcount(wetmask & lattice_mask(0, 0));
     const int s_j = __builtin_popcount(wetmask & lattice_mask(1, 2)) - __builtin_popcount(wetmask & lattice_mask(1, 0));
     const int s_k = __builtin_popcount(wetmask & lattice_mask(2, 2)) - __builtin_popcount(wetmask & lattice_mask(2, 0));
-    const double inv_cnt = (!dry && !full && cnt > 0) ? rcp64((double)cnt) : 0.0;    // fully in / dry: cob = position
+    // fully in: all 27 wet, the index sums vanish by symmetry, cob = position; dry: nothing wet, sums 0, count 0 -> 1
+    const double inv_cnt = rcp64((double)(cnt > 1 ? cnt : 1));
     const double lbx = hx * ((double)s_i * inv_cnt), lby = hy * ((double)s_j * inv_cnt), lbz = hz * ((double)s_k * inv_cnt);
     o.armb_x = r00 * lbx + r01 * lby + r02 * lbz;
     o.armb_y = r10 * lbx + r11 * lby + r12 * lbz;
     o.armb_z = r20 * lbx + r21 * lby + r22 * lbz;
 
     // ---- A5: buoyancy (:282) ----
-    o.buoy_z = rho * (ratio * vol) * g;
+    const double wet_mass = (rho * vol) * ratio;        // rho * displaced volume (shared with the added-mass factors)
+    o.buoy_z = wet_mass * g;
 
-    // ---- A6: speed and direction (:285-289) ----
+    // ---- A6: speed and direction (:285-289): |v| and 1/|v| from one seed ----
     const double vx = b.vx, vy = b.vy, vz = b.vz;
-    const double speed = sqrt64(vx * vx + vy * vy + vz * vz);
+    const double v2 = vx * vx + vy * vy + vz * vz;
+    const double rs = rsqrt64(v2);
+    const double speed = v2 * rs;
     const bool moving = speed > kSpeedEps;
-    const double inv_speed = moving ? rcp64(speed) : 0.0;
+    const double inv_speed = moving ? rs : 0.0;
     const double nx = vx * inv_speed, ny = vy * inv_speed, nz = vz * inv_speed;          // v_hat (0 at rest)
 
     // ---- A7: projected area + centre of pressure (:108-143) ----
     // u = R^T v_hat; face (axis a, sign s) has alignment -s*u_a and centre height p_z + s*e_a: the face of axis a that
-    // opposes the flow has s_a = -sign(u_a).  At rest u = 0 and nothing counts (N1 completion: area 0, cop = cob).
+    // opposes the flow has s_a = -sign(u_a).  At rest u = 0 and nothing counts (N1 completion: area 0, cop = cob); a
+    // face with u_a = 0 contributes |u_a| * A = 0 by itself.
     const double ux = r00 * nx + r10 * ny + r20 * nz;
     const double uy = r01 * nx + r11 * ny + r21 * nz;
     const double uz = r02 * nx + r12 * ny + r22 * nz;
     const double fsx = (ux < 0.0) ? 1.0 : -1.0, fsy = (uy < 0.0) ? 1.0 : -1.0, fsz = (uz < 0.0) ? 1.0 : -1.0;
+    const double fhx = fsx * hx, fhy = fsy * hy, fhz = fsz * hz;
     // (the six face centres ARE lattice points - (+-1,0,0), (0,+-1,0), (0,0,+-1) - so "centre below the surface" is a
     // bit of the keypoint mask: the same value p_z +- e_a, the same sign bit)
     const bool wfx = wetmask & ((ux < 0.0) ? lattice_bit(1, 0, 0) : lattice_bit(-1, 0, 0));
     const bool wfy = wetmask & ((uy < 0.0) ? lattice_bit(0, 1, 0) : lattice_bit(0, -1, 0));
     const bool wfz = wetmask & ((uz < 0.0) ? lattice_bit(0, 0, 1) : lattice_bit(0, 0, -1));
-    const double fax = ((ux != 0.0) && wfx) ? fabs(ux) * (dy * dz) : 0.0;
-    const double fay = ((uy != 0.0) && wfy) ? fabs(uy) * (dx * dz) : 0.0;
-    const double faz = ((uz != 0.0) && wfz) ? fabs(uz) * axy_ : 0.0;
+    const double fax = wfx ? fabs(ux) * (dy * dz) : 0.0;
+    const double fay = wfy ? fabs(uy) * (dx * dz) : 0.0;
+    const double faz = wfz ? fabs(uz) * axy_ : 0.0;
     const double area = fax + fay + faz;
     const bool has_area = area > kAreaEps;
     const double inv_area = has_area ? rcp64(area) : 0.0;
     // body-frame CoP arm: sum of (face centre x its share of the area); without area cop = cob (:115,140).  The
-    // choice is made on the body-frame vector, so one rotation serves both cases.
-    const double lpx = has_area ? fsx * hx * (fax * inv_area) : lbx;
-    const double lpy = has_area ? fsy * hy * (fay * inv_area) : lby;
-    const double lpz = has_area ? fsz * hz * (faz * inv_area) : lbz;
+    // choice is made on the body-frame vector, so one rotation serves both cases: the face term is exactly 0 without
+    // area (inv_area = 0), and the CoB arm enters with weight 0 or 1.
+    const double use_cob = has_area ? 0.0 : 1.0;
+    const double lpx = __builtin_fma(use_cob, lbx, fhx * (fax * inv_area));
+    const double lpy = __builtin_fma(use_cob, lby, fhy * (fay * inv_area));
+    const double lpz = __builtin_fma(use_cob, lbz, fhz * (faz * inv_area));
     o.armp_x = r00 * lpx + r01 * lpy + r02 * lpz;
     o.armp_y = r10 * lpx + r11 * lpy + r12 * lpz;
     o.armp_z = r20 * lpx + r21 * lpy + r22 * lpz;
 
     // ---- A8: hybrid drag (:146-182).  -(1/2 rho s^2 Cd A) v_hat = -(1/2 rho s Cd A) v, so both parts scale v ----
+    // (no select on the linear quadratic term: at rest the area is 0 already)
     const double half_rho = 0.5 * rho;
-    const double lin_quad = moving ? half_rho * speed * ((double)b.cd_lin * area) : 0.0;
-    const double lin_scale = (speed < kLowSpeed) ? speed * 5.0 : 1.0;                     // min(1, s / 0.2)
+    const double hrs = half_rho * speed;
+    const double lin_quad = hrs * ((double)b.cd_lin * area);
+    const double lin_scale = fmin(1.0, speed * 5.0);                                      // min(1, s / 0.2)
     o.lin_k = -(lin_quad + (double)b.damp_lin * lin_scale) * ratio;
     o.drag_fx = o.lin_k * vx; o.drag_fy = o.lin_k * vy; o.drag_fz = o.lin_k * vz;
     const double ox = b.wx, oy = b.wy, oz = b.wz;
     const double wspeed = sqrt64(ox * ox + oy * oy + oz * oz);
     const double ang_quad = (wspeed > kSpeedEps) ? half_rho * wspeed * ((double)b.cd_ang * vol) : 0.0;   // note: volume, not area
-    const double ang_scale = (wspeed < kLowSpeed) ? wspeed * 5.0 : 1.0;
+    const double ang_scale = fmin(1.0, wspeed * 5.0);
     o.ang_k = -(ang_quad + (double)b.damp_ang * ang_scale) * ratio;
     o.drag_tx = o.ang_k * ox; o.drag_ty = o.ang_k * oy; o.drag_tz = o.ang_k * oz;
 
     // ---- A9: lift (:185-217) ----
-    // up = R[:,2]; d = clamp(-up.v_hat) = clamp(-u_z); C_L = sin(2 asin d) = 2 d sqrt((1-d)(1+d));
+    // up = R[:,2]; d = clamp(-up.v_hat) = clamp(-u_z); C_L = sin(2 asin d) = 2 d sqrt(1 - d^2);
     // dir = (axis / |axis|) x v_hat with axis = v_hat x up; nothing if speed < 1e-6 or |axis| < 1e-6.
     {
-        const double d = fmin(1.0, fmax(-1.0, -uz));
         const double axx = ny * r22 - nz * r12, axy = nz * r02 - nx * r22, axz = nx * r12 - ny * r02;
         const double n2 = axx * axx + axy * axy + axz * axz;
         const bool lift_on = !(speed < kSpeedEps) && !(n2 < kAxisEps * kAxisEps);
-        // C_L / |axis| from ONE reciprocal and ONE square root:  2 d sqrt((1-d)(1+d) / |axis|^2)
-        const double cl_over_n = lift_on ? 2.0 * d * sqrt64(fmax(0.0, (1.0 - d) * (1.0 + d)) * rcp64(n2)) : 0.0;
-        const double k = (half_rho * (speed * speed) * (area * (double)b.lift)) * (cl_over_n * ratio);
-        // axis x v_hat = up |v_hat|^2 - v_hat (v_hat . up) = up - u_z v_hat      (|v_hat|^2 = 1 to 1e-16)
+        // C_L / |axis| = 2 d sqrt(q / |axis|^2) with q = max(0, 1 - d^2) = q * rsqrt(q |axis|^2): ONE seed.  The fma gives
+        // 1 - d^2 correctly rounded (no cancellation near |d| = 1); |d| > 1 (a non-unit quaternion) makes q = 0, which
+        // is what the reference's clamp of d to [-1, 1] gives: sin(2 asin(+-1)) = 0.
+        const double q = fmax(0.0, __builtin_fma(-uz, uz, 1.0));
+        const double cl_over_n = lift_on ? -2.0 * uz * (q * rsqrt64(q * n2)) : 0.0;
+        const double k = (hrs * speed * (area * (double)b.lift)) * (cl_over_n * ratio);
+        // axis x v_hat = up |v_hat|^2 - v_hat (v_hat . up) = up - u_z v_hat      (|v_hat|^2 = 1 to 1e-13)
         o.lift_fx = k * __builtin_fma(-uz, nx, r02); o.lift_fy = k * __builtin_fma(-uz, ny, r12); o.lift_fz = k * __builtin_fma(-uz, nz, r22);
     }
 
     // ---- A10: added mass (:220-253; diagonal of numba_hydrodynamics_wrapper.py:101-112) ----
     {
-        double ax, ay, az, bx, by, bz;                                          // world-frame accelerations
-        float am_lin, am_ang;
-        late(area, ax, ay, az, bx, by, bz, am_lin, am_ang);
         double alx, aly, alz, blx, bly, blz;                                    // accelerations in the "local" frame
         if (warp) {                                                             // N3: quat_rotate = R (warp_hydrodynamics.py:216-217)
             alx = r00 * ax + r01 * ay + r02 * az; aly = r10 * ax + r11 * ay + r12 * az; alz = r20 * ax + r21 * ay + r22 * az;
@@ -299,24 +337,15 @@ HYDRO_FN Body solve_body_with(const BodyIn& b, Late&& late, double rho, double g
             alx = r00 * ax + r10 * ay + r20 * az; aly = r01 * ax + r11 * ay + r21 * az; alz = r02 * ax + r12 * ay + r22 * az;
             blx = r00 * bx + r10 * by + r20 * bz; bly = r01 * bx + r11 * by + r21 * bz; blz = r02 * bx + r12 * by + r22 * bz;
         }
-        const double rv = vol * rho;
-        const double kf = -(rv * (double)am_lin) * ratio, kt = -(rv * (double)am_ang) * ratio;
+        const double rv = wet_mass * acc_scale;
+        const double kf = -(rv * (double)b.am_lin), kt = -(rv * (double)b.am_ang);
         const double glx = kf * alx, gly = kf * aly, glz = kf * alz;
-        const double tlx = kt * (dy * dy + dz * dz) * blx, tly = kt * (dx * dx + dz * dz) * bly, tlz = kt * (dx * dx + dy * dy) * blz;
+        const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+        const double tlx = kt * (dy2 + dz2) * blx, tly = kt * (dx2 + dz2) * bly, tlz = kt * (dx2 + dy2) * blz;
         o.am_fx = r00 * glx + r01 * gly + r02 * glz; o.am_fy = r10 * glx + r11 * gly + r12 * glz; o.am_fz = r20 * glx + r21 * gly + r22 * glz;
         o.am_tx = r00 * tlx + r01 * tly + r02 * tlz; o.am_ty = r10 * tlx + r11 * tly + r12 * tlz; o.am_tz = r20 * tlx + r21 * tly + r22 * tlz;
     }
     return o;
-}
-
-// A1-A11 with the accelerations and the added-mass coefficients at hand (component mode, host instantiation).
-HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, double bx, double by, double bz,
-                         double rho, double g, bool warp = false)
-{
-    return solve_body_with(b, [&](double, double& oax, double& oay, double& oaz, double& obx, double& oby, double& obz,
-                                  float& am_lin, float& am_ang) {
-        oax = ax; oay = ay; oaz = az; obx = bx; oby = by; obz = bz; am_lin = b.am_lin; am_ang = b.am_ang;
-    }, rho, g, warp);
 }
 
 struct Wrench {
@@ -337,39 +366,25 @@ HYDRO_FN Wrench assemble_wrench(const Body& o, float mass)
     // The clamp factor multiplies the finished sums - nothing cancels after it - so it is the one quantity evaluated
     // in fp32 (v_sqrt_f32 / v_rcp_f32, 1 ulp each): ~2e-7 on the results of the bodies it applies to (scale < 1).
     const float f_mag = fast_sqrt((float)(fx * fx + fy * fy + fz * fz));
-    const float scale = fminf(1.0f, (mass * (float)kMaxAccel) * fast_rcp(f_mag + (float)kClampEps));
+    const float clamp = fminf(1.0f, (mass * (float)kMaxAccel) * fast_rcp(f_mag + (float)kClampEps));
+    // A4: a dry body gets EXACT zeros - its factor is 0 and 0 wins the product whatever the other operand is
+    const float scale = o.wet ? clamp : 0.0f;
     Wrench w;
-    w.fx = o.wet ? (float)fx * scale : 0.0f; w.fy = o.wet ? (float)fy * scale : 0.0f; w.fz = o.wet ? (float)fz * scale : 0.0f;
-    w.tx = o.wet ? (float)tx * scale : 0.0f; w.ty = o.wet ? (float)ty * scale : 0.0f; w.tz = o.wet ? (float)tz * scale : 0.0f;
-    w.k_lin = o.wet ? (float)o.lin_k * scale : 0.0f;
-    w.k_ang = o.wet ? (float)o.ang_k * scale : 0.0f;
+    w.fx = mul_zero_wins(scale, (float)fx); w.fy = mul_zero_wins(scale, (float)fy); w.fz = mul_zero_wins(scale, (float)fz);
+    w.tx = mul_zero_wins(scale, (float)tx); w.ty = mul_zero_wins(scale, (float)ty); w.tz = mul_zero_wins(scale, (float)tz);
+    w.k_lin = mul_zero_wins(scale, (float)o.lin_k);
+    w.k_ang = mul_zero_wins(scale, (float)o.ang_k);
     return w;
 }
 
 // One body of the fused entry points: A13 (finite-difference acceleration from the previous-step velocity,
-// hydrodynamics_behavior.py:196-202) + A1-A11 + A14-A15.  inv_dt = 1/dt in fp64 (dt is a double through the C ABI).
+// hydrodynamics_behavior.py:196-202) + A1-A11 + A14-A15.  inv_dt = 1/dt in fp64 (dt is a double through the C ABI); the
+// velocity differences are exact in fp64 and 1/dt scales the two added-mass factors (solve_body).
 HYDRO_FN Wrench solve_wrench(const BodyIn& b, const float (&pv)[6], float mass, double rho, double g, double inv_dt, bool warp)
 {
-    const double ax = ((double)b.vx - (double)pv[0]) * inv_dt, ay = ((double)b.vy - (double)pv[1]) * inv_dt, az = ((double)b.vz - (double)pv[2]) * inv_dt;
-    const double bx = ((double)b.wx - (double)pv[3]) * inv_dt, by = ((double)b.wy - (double)pv[4]) * inv_dt, bz = ((double)b.wz - (double)pv[5]) * inv_dt;
-    return assemble_wrench(solve_body(b, ax, ay, az, bx, by, bz, rho, g, warp), mass);
-}
-
-// The same with the late inputs fetched by the caller's `load(anchor, pv, am_lin, am_ang, mass)` at the point of use
-// (see solve_body_with): the previous-step velocity, the two added-mass coefficients and the mass are what the last
-// third of the evaluation needs and nothing before it does.  Same expressions, same bits as solve_wrench.
-template <class LateLoad>
-HYDRO_FN Wrench solve_wrench_late(const BodyIn& b, LateLoad&& load, double rho, double g, double inv_dt, bool warp)
-{
-    float mass = 0.0f;
-    const Body o = solve_body_with(b, [&](double anchor, double& ax, double& ay, double& az, double& bx, double& by, double& bz,
-                                          float& am_lin, float& am_ang) {
-        float pv[6];
-        load(anchor, pv, am_lin, am_ang, mass);
-        ax = ((double)b.vx - (double)pv[0]) * inv_dt; ay = ((double)b.vy - (double)pv[1]) * inv_dt; az = ((double)b.vz - (double)pv[2]) * inv_dt;
-        bx = ((double)b.wx - (double)pv[3]) * inv_dt; by = ((double)b.wy - (double)pv[4]) * inv_dt; bz = ((double)b.wz - (double)pv[5]) * inv_dt;
-    }, rho, g, warp);
-    return assemble_wrench(o, mass);
+    const double ax = (double)b.vx - (double)pv[0], ay = (double)b.vy - (double)pv[1], az = (double)b.vz - (double)pv[2];
+    const double bx = (double)b.wx - (double)pv[3], by = (double)b.wy - (double)pv[4], bz = (double)b.wz - (double)pv[5];
+    return assemble_wrench(solve_body(b, ax, ay, az, bx, by, bz, inv_dt, rho, g, warp), mass);
 }
 
 // The calculator surface (calculate_hydrodynamic_forces, numba_hydrodynamics_wrapper.py:34-53): the eight vectors

@@ -224,7 +224,10 @@ __device__ __forceinline__ hydro::Wrench body_wrench(const float (&s)[HYDRO_STAT
 // Algorithmic traffic per body: 52 B state + 24 B previous velocity + 44 B (30 B
 // with fp16 coefficients) parameters in, 24 B wrench out (+24 B if WRITE_PREV).
 // --------------------------------------------------------------------------
-template <int BLOCK, int VEC, bool HALF, bool WRITE_PREV, bool NT>
+// WARP (every wrench kernel): the semantics of the reference's Warp twin (HYDRO_SEM_WARP) as a COMPILE-TIME switch.  As
+// a run-time flag it cost the path everybody takes 12 v_cndmask_b32 (the compiler turns "R or R^T" into selects of the
+// six off-diagonal matrix entries rather than branching around 18 multiply-adds).
+template <int BLOCK, int VEC, bool HALF, bool WRITE_PREV, bool NT, bool WARP>
 __global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
 {
     // Precondition (host side, launch_soa): a.n is a multiple of VEC; the <= VEC-1 leftover
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
         for (int f = 0; f < 3; ++f) d[f] = dm[f][j];
 #pragma unroll
         for (int f = 0; f < 7; ++f) c[f] = cf[f][j];
-        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, a.warp != 0);
+        const hydro::Wrench w = body_wrench(s, p, d, c, ms[j], a.rho, a.g, a.inv_dt, WARP);
         out[0][j] = w.fx; out[1][j] = w.fy; out[2][j] = w.fz;
         out[3][j] = w.tx; out[4][j] = w.ty; out[5][j] = w.tz;
     }
@@ -346,7 +349,7 @@ __device__ __forceinline__ void load_tile_records(const TiledArgs& a, uint32_t t
 // KE = true (BLOCK 256 only): the kernel also samples the kinetic energy of the bodies it holds - the state it READS,
 // i.e. the state after the previous step - and leaves one fp64 pair per block in `ke_partials` ([2][ke_stride]) for
 // the fixed-order second stage: no second pass over the state ("reduced in-kernel").
-template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT, bool KE = false>
+template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT, bool KE, bool WARP>
 __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
                                                              uint32_t st_stride, uint32_t pv_stride, uint32_t out_stride, uint32_t pvo_stride,
                                                              uint32_t n, int warp, double rho, double g, double inv_dt,
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
         const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
         float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
         load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
-        const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+        const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, WARP);
         if constexpr (KE)
             hydro::kinetic_energy(s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], d[0], d[1], d[2], mass,
                                   ke_rotational != 0, ke_lin, ke_rot);
@@ -666,7 +669,7 @@ HYDRO_WIDE_ACCESS(f2_a8)
 HYDRO_WIDE_ACCESS(f4_a16)
 #undef HYDRO_WIDE_ACCESS
 
-template <bool HALF, bool NT>
+template <bool HALF, bool NT, bool WARP>
 __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* k_pos, const float* k_quat, const float* k_vel, float* k_force, float* k_torque,
                                                                   float* k_pv, const float* k_prm, int quat_xyzw, uint32_t n,      // 16 dwords: preloaded
                                                                   int warp, double rho, double g, double inv_dt)
@@ -702,7 +705,7 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
         for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(k_prm, qo + (3 + f) * 256u));
         mass = ldg<NT>(at<float>(k_prm, qo, 10 * 256u));
     }
-    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, warp != 0);
+    const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, WARP);
 #pragma unroll
     for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(k_pv, po, f * 256u), s[7 + f]);
     f3_a4 fo, to;
@@ -837,7 +840,7 @@ __global__ void __launch_bounds__(kBlock) components_kernel(const CompArgs a)
     b.damp_lin = load_coef1<HALF>(a.coef[2], i); b.damp_ang = load_coef1<HALF>(a.coef[3], i);
     b.lift = load_coef1<HALF>(a.coef[4], i); b.am_lin = load_coef1<HALF>(a.coef[5], i);
     b.am_ang = load_coef1<HALF>(a.coef[6], i);
-    const hydro::Body o = hydro::solve_body(b, a.acc[0][i], a.acc[1][i], a.acc[2][i], a.acc[3][i], a.acc[4][i], a.acc[5][i],
+    const hydro::Body o = hydro::solve_body(b, a.acc[0][i], a.acc[1][i], a.acc[2][i], a.acc[3][i], a.acc[4][i], a.acc[5][i], 1.0,
                                             a.rho, a.g, a.warp != 0);
     const hydro::Components c = hydro::round_components(o, b, a.warp != 0);
     // reference order: buoyancy F, drag F, lift F, drag T, added-mass F, added-mass T, cob, cop (world space; zeros
@@ -890,7 +893,7 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
     }
     b.cd_lin = c[0]; b.cd_ang = c[1]; b.damp_lin = c[2]; b.damp_ang = c[3]; b.lift = c[4]; b.am_lin = c[5]; b.am_ang = c[6];
     const hydro::Body o = hydro::solve_body(b, a.lin_acc[3 * i], a.lin_acc[3 * i + 1], a.lin_acc[3 * i + 2],
-                                            a.ang_acc[3 * i], a.ang_acc[3 * i + 1], a.ang_acc[3 * i + 2], a.rho, a.g, a.warp != 0);
+                                            a.ang_acc[3 * i], a.ang_acc[3 * i + 1], a.ang_acc[3 * i + 2], 1.0, a.rho, a.g, a.warp != 0);
     const hydro::Components r = hydro::round_components(o, b, a.warp != 0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1074,7 +1077,7 @@ struct FusedArgs {
 };
 
 // KE = true: also samples the kinetic energy of the state it WRITES (the state after this step), see wrench_tiled_kernel.
-template <bool HALF, bool NT, bool IMPLICIT, bool KE = false>
+template <bool HALF, bool NT, bool IMPLICIT, bool KE, bool WARP>
 __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_so, float* k_out,
                                                                  uint32_t st_stride, uint32_t pv_stride, uint32_t so_stride, uint32_t out_stride,
                                                                  uint32_t n, int warp, float dt, double rho, double g, double inv_dt,
@@ -1096,7 +1099,7 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k
         const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
         float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
         load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
-        const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, a.warp != 0);
+        const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, WARP);
         const float k_lin = w.k_lin, k_ang = w.k_ang;     // used by the implicit form only
         const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
         float o[HYDRO_STATE_FIELDS];
@@ -1250,17 +1253,24 @@ constexpr int64_t kNtMinBodies = 131072;
 constexpr int64_t kFusedTemporalMin = 458752, kFusedTemporalMax = 2621440;
 constexpr int64_t kBigBlockMinBodies = 2097152;
 
-template <int BLOCK, int VEC, bool WRITE_PREV>
-void launch_soa_b(hydro_engine* h, const SoaArgs& a, hipStream_t s, bool nt)
+template <int BLOCK, int VEC, bool WRITE_PREV, bool WARP>
+void launch_soa_w(hydro_engine* h, const SoaArgs& a, hipStream_t s, bool nt)
 {
     const dim3 grid(grid_for(a.n, BLOCK * VEC)), block(BLOCK);
     if (h->half_coeffs) {
-        if (nt) hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, true, WRITE_PREV, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, true, WRITE_PREV, false>), grid, block, 0, s, a);
+        if (nt) hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, true, WRITE_PREV, true, WARP>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, true, WRITE_PREV, false, WARP>), grid, block, 0, s, a);
     } else {
-        if (nt) hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, false, WRITE_PREV, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, false, WRITE_PREV, false>), grid, block, 0, s, a);
+        if (nt) hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, false, WRITE_PREV, true, WARP>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wrench_soa_kernel<BLOCK, VEC, false, WRITE_PREV, false, WARP>), grid, block, 0, s, a);
     }
+}
+
+template <int BLOCK, int VEC, bool WRITE_PREV>
+void launch_soa_b(hydro_engine* h, const SoaArgs& a, hipStream_t s, bool nt)
+{
+    if (h->semantics == HYDRO_SEM_WARP) launch_soa_w<BLOCK, VEC, WRITE_PREV, true>(h, a, s, nt);
+    else launch_soa_w<BLOCK, VEC, WRITE_PREV, false>(h, a, s, nt);
 }
 
 template <int VEC, bool WRITE_PREV>
@@ -1686,7 +1696,8 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
     }
 #define HYDRO_TILED_ARGS a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt, \
         h->ke_partials, h->ke_stride, ke_rotational
-#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT>), grid, blk, lds, s, HYDRO_TILED_ARGS)
+#define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) do { if (a.warp) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT, false, true>), grid, blk, lds, s, HYDRO_TILED_ARGS); \
+        else hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT, false, false>), grid, blk, lds, s, HYDRO_TILED_ARGS); } while (0)
 #define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
 #define HYDRO_TILED_WP(BLOCK, HALF) do { if (own_prev) HYDRO_TILED_NT(BLOCK, HALF, true); else HYDRO_TILED_NT(BLOCK, HALF, false); } while (0)
 #define HYDRO_TILED_HALF(BLOCK) do { if (h->half_coeffs) HYDRO_TILED_WP(BLOCK, true); else HYDRO_TILED_WP(BLOCK, false); } while (0)
@@ -1705,11 +1716,13 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
 #else
     if (ke_out) {
         // the sampling variant: same body, same bits, plus one fp64 pair per block; then the fixed-order second stage
-#define HYDRO_TILED_KE(HALF, WP) do { if (nt) hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, true, true>), grid, blk, lds, s, HYDRO_TILED_ARGS); \
-                                      else hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, false, true>), grid, blk, lds, s, HYDRO_TILED_ARGS); } while (0)
+#define HYDRO_TILED_KE_W(HALF, WP, WARP) do { if (nt) hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, true, true, WARP>), grid, blk, lds, s, HYDRO_TILED_ARGS); \
+                                              else hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, false, true, WARP>), grid, blk, lds, s, HYDRO_TILED_ARGS); } while (0)
+#define HYDRO_TILED_KE(HALF, WP) do { if (a.warp) HYDRO_TILED_KE_W(HALF, WP, true); else HYDRO_TILED_KE_W(HALF, WP, false); } while (0)
         if (h->half_coeffs) { if (own_prev) HYDRO_TILED_KE(true, true); else HYDRO_TILED_KE(true, false); }
         else { if (own_prev) HYDRO_TILED_KE(false, true); else HYDRO_TILED_KE(false, false); }
 #undef HYDRO_TILED_KE
+#undef HYDRO_TILED_KE_W
     } else if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
 #endif
 #undef HYDRO_TILED_HALF
@@ -1795,13 +1808,15 @@ int step_fused_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t sta
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
 #define HYDRO_FUSED_ARGS a.st, a.pv, a.prm, fa.so, a.out, a.st_stride, a.pv_stride, fa.so_stride, a.out_stride, a.n, a.warp, fa.dt, a.rho, a.g, a.inv_dt, \
         h->ke_partials, h->ke_stride, ke_rotational
-#define HYDRO_FUSED_I(HALF, NT, KE) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true, KE>), grid, blk, 0, s, HYDRO_FUSED_ARGS); \
-                                         else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false, KE>), grid, blk, 0, s, HYDRO_FUSED_ARGS); } while (0)
+#define HYDRO_FUSED_W(HALF, NT, KE, WARP) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true, KE, WARP>), grid, blk, 0, s, HYDRO_FUSED_ARGS); \
+                                               else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false, KE, WARP>), grid, blk, 0, s, HYDRO_FUSED_ARGS); } while (0)
+#define HYDRO_FUSED_I(HALF, NT, KE) do { if (a.warp) HYDRO_FUSED_W(HALF, NT, KE, true); else HYDRO_FUSED_W(HALF, NT, KE, false); } while (0)
 #define HYDRO_FUSED(HALF, NT) do { if (ke_out) HYDRO_FUSED_I(HALF, NT, true); else HYDRO_FUSED_I(HALF, NT, false); } while (0)
     if (h->half_coeffs) { if (nt) HYDRO_FUSED(true, true); else HYDRO_FUSED(true, false); }
     else { if (nt) HYDRO_FUSED(false, true); else HYDRO_FUSED(false, false); }
 #undef HYDRO_FUSED
 #undef HYDRO_FUSED_I
+#undef HYDRO_FUSED_W
 #undef HYDRO_FUSED_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return ke_out ? ke_finish(h, n, ke_out, s) : HYDRO_OK;
@@ -1905,13 +1920,11 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
 #define HYDRO_AOS_ARGS a.pos, a.quat, a.vel, a.force, a.torque, a.pv, a.prm, a.quat_xyzw, (uint32_t)a.n, a.warp, a.rho, a.g, a.inv_dt
 #if !HYDRO_AB_AOS_LDS
-    if (h->half_coeffs) {
-        if (nt) hipLaunchKernelGGL((wrench_aos_direct_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-        else hipLaunchKernelGGL((wrench_aos_direct_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-    } else {
-        if (nt) hipLaunchKernelGGL((wrench_aos_direct_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-        else hipLaunchKernelGGL((wrench_aos_direct_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-    }
+#define HYDRO_AOS_W(HALF, NT) do { if (a.warp) hipLaunchKernelGGL((wrench_aos_direct_kernel<HALF, NT, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS); \
+                                   else hipLaunchKernelGGL((wrench_aos_direct_kernel<HALF, NT, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS); } while (0)
+    if (h->half_coeffs) { if (nt) HYDRO_AOS_W(true, true); else HYDRO_AOS_W(true, false); }
+    else { if (nt) HYDRO_AOS_W(false, true); else HYDRO_AOS_W(false, false); }
+#undef HYDRO_AOS_W
 #else
     if (h->half_coeffs) {
         if (nt) hipLaunchKernelGGL((wrench_aos_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);

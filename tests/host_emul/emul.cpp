@@ -30,7 +30,7 @@ extern "C" int emul_wrench(int64_t n, const float* state, const float* prev, con
         const hydro::Wrench w = hydro::solve_wrench(b, pv, pr[10], rho64, g64, inv_dt, g_warp != 0);   // as the wrench kernels do
         net_f[3 * i] = w.fx; net_f[3 * i + 1] = w.fy; net_f[3 * i + 2] = w.fz;
         net_t[3 * i] = w.tx; net_t[3 * i + 1] = w.ty; net_t[3 * i + 2] = w.tz;
-        const hydro::Body o = hydro::solve_body(b, 0, 0, 0, 0, 0, 0, rho64, g64, g_warp != 0);
+        const hydro::Body o = hydro::solve_body(b, 0, 0, 0, 0, 0, 0, 1.0, rho64, g64, g_warp != 0);
         ratio[i] = o.wet ? (float)o.ratio : 0.0f;
     }
     return 0;
@@ -42,9 +42,9 @@ extern "C" int emul_body(const float* s, const float* pv, const float* pr, doubl
 {
     const double inv_dt = 1.0 / dt;
     const hydro::BodyIn b = body_in(s, pr);
-    const hydro::Body o = hydro::solve_body(b, ((double)b.vx - pv[0]) * inv_dt, ((double)b.vy - pv[1]) * inv_dt, ((double)b.vz - pv[2]) * inv_dt,
-                                            ((double)b.wx - pv[3]) * inv_dt, ((double)b.wy - pv[4]) * inv_dt, ((double)b.wz - pv[5]) * inv_dt,
-                                            rho64, g64, g_warp != 0);
+    const hydro::Body o = hydro::solve_body(b, (double)b.vx - pv[0], (double)b.vy - pv[1], (double)b.vz - pv[2],
+                                            (double)b.wx - pv[3], (double)b.wy - pv[4], (double)b.wz - pv[5],
+                                            inv_dt, rho64, g64, g_warp != 0);
     const hydro::Components c = hydro::round_components(o, b, g_warp != 0);
     for (int k = 0; k < 8; ++k)
         for (int a = 0; a < 3; ++a) out[3 * k + a] = c.v[k][a];
