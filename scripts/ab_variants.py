@@ -83,7 +83,7 @@ for kind, n, coeff, sets in CASES:
                 res[nm].append(e0.elapsed_time(e1) * 1e3 / K)
     for nm in names:
         v = res[nm]
-        say(f"{kind} n={n} {coeff} {nm:12s}: median {statistics.median(v):7.2f} us  min {min(v):7.2f}  max {max(v):7.2f}")
+        say(f"{kind} n={n} {coeff} {nm:12s}: median {statistics.median(v):7.2f} us  min {min(v):7.2f}  max {max(v):7.2f}   rounds: " + " ".join(f"{x:.1f}" for x in v))
     for nm in names:
         for R in reps[nm]: R.engine.close()
     del reps

@@ -40,8 +40,17 @@
 #ifndef HYDRO_AB_TILED_WAVES         // A/B knob: minimum resident waves per SIMD asked of the tiled wrench kernel (0 = what it needs)
 #define HYDRO_AB_TILED_WAVES 0
 #endif
+// Default: AT MOST 4 waves per SIMD.  After the instruction diet of round 3 two instantiations of the tiled kernel need
+// only 95 VGPRs and would run 5 waves per SIMD; interleaved A/B on three boxes: the same code at
+// 4 waves is 0.1-0.3 us faster at 1 M bodies (22.31-22.56 vs 22.39-22.86 us) - the fifth wave buys no latency hiding
+// that the kernel lacks and costs a little in the memory system.
+#ifndef HYDRO_AB_TILED_WAVES_MAX
+#define HYDRO_AB_TILED_WAVES_MAX 4
+#endif
 #if HYDRO_AB_TILED_WAVES
 #define HYDRO_TILED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(HYDRO_AB_TILED_WAVES)))
+#elif HYDRO_AB_TILED_WAVES_MAX
+#define HYDRO_TILED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(1, HYDRO_AB_TILED_WAVES_MAX)))
 #else
 #define HYDRO_TILED_OCC_ATTR
 #endif

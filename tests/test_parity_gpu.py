@@ -393,6 +393,33 @@ def test_engine_holds_68_bytes_per_body_until_a_plain_soa_entry_is_used(native_b
     eng.close()
 
 
+def test_plain_soa_step_is_capturable_after_reserve_soa(native_built):
+    """The first call of a plain-SoA entry allocates the engine's plain copies (not capturable); `reserve_soa` makes
+    them up front, after which the entry is as capture-safe as the others: graph replay == eager call, bit for bit."""
+    fx = load_golden("c2")
+    n, dt = 4096, float(fx["dt"])
+    eng = HydroEngine(n, DEV, float(fx["rho"]), float(fx["g"]))
+    eng.set_params(fx["params"][:n])
+    eng.reserve_soa()
+    st, pv = soa(fx["state"][:n]), soa(fx["prev"][:n])
+    out = torch.zeros((6, n), device=DEV)
+    stream = torch.cuda.Stream(DEV)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        with torch.cuda.graph(g, stream=stream):
+            eng.step_wrench(st, dt, out=out, prev=pv)          # the very first plain-SoA call of this engine, captured
+        g.replay()
+        stream.synchronize()
+    eager = eng.step_wrench(st, dt, prev=pv)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    f, t = run_ext(fx["state"][:n], fx["prev"][:n], fx["params"][:n], float(fx["rho"]), float(fx["g"]), dt)
+    assert np.array_equal(out.cpu().numpy().T, np.concatenate([f, t], axis=1))
+    del g
+    eng.close()
+
+
 def _integrate_ref(state, wrench, params, g, dt):
     s = state.astype(np.float64); w6 = wrench.astype(np.float64); p = params.astype(np.float64)
     m = p[:, 10]; d = p[:, :3]
