@@ -541,6 +541,19 @@ def bound_probes_leg(n: int, dev, stream):
     return out
 
 
+def clock_probes_leg(n: int, dev, stream):
+    """The shader clock this box holds under the kernel's whole body, under its memory traffic alone and under its
+    arithmetic alone (scripts/probes.py clock_probes: s_memtime / s_memrealtime stamped by every wave, after 1 s of
+    back-to-back launches of each kind).  The wrench kernels are co-limited at the combined-load clock; boxes differ in
+    how far they throttle there, and that - not the code - is the spread of `ms_per_step` between runs."""
+    from scripts import probes
+    c = probes.clock_probes(n, dev, stream, seconds=1.0)
+    return {"n": n, "whole_body_ghz": c["whole_body"]["ghz"], "memory_only_ghz": c["memory_only"]["ghz"],
+            "compute_only_ghz": c["compute_only"]["ghz"],
+            "wave_lifetime_us": {k: v["wave_lifetime_us"] for k, v in c.items()},
+            "how": "in-kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the waves of 50 launches"}
+
+
 def plugin_c3_rate(steps: int = 2000):
     """BASELINE config 3 through the PLUGIN surface: 19 456 prims (1 024 SILVER2 robots x 19 links), one
     HydrodynamicsBehavior instance each, scene mode (ONE physics-step subscription for the group, one
@@ -885,6 +898,7 @@ def main():
             # which bound binds: memory-only / compute-only probes beside the kernels themselves (verdict r2 item 2)
             guarded("bound_probes_1m", bound_probes_leg, 1048576, dev, stream)
             guarded("bound_probes_4m", bound_probes_leg, 4194304, dev, stream)
+            guarded("clocks_1m", clock_probes_leg, 1048576, dev, stream)
             guarded("c2_4096", quick_rate, "c2", 4096, "f32", dev, stream, steps=200)
             guarded("c3_19456", quick_rate, "c3", 19456, "f32", dev, stream, steps=200)
             guarded("c4_shard_32768", quick_rate, "c4", 32768, "f32", dev, stream, steps=200)
