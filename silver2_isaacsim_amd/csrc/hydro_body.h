@@ -9,11 +9,14 @@
 //     rearrangement of fp32 arithmetic removes that.  Round 1 of this repository did everything that can be done
 //     in fp32 (fp64 islands for the worst cancellations, structural-zero forms, exact identities in |q|^2 - 1) and
 //     still had 48 of 692 M margin-gated evaluations above 1e-5.
-//   * the kernels are HBM-bound (122-136 B per body against ~600 VALU instructions): the MI355X has 157 TFLOP/s of
-//     fp32 and 79 TFLOP/s of fp64 VALU behind 8 TB/s.  Measured: the all-fp64 body costs about
-//     what the fp32 + fp64-island body it replaces cost at 1 M bodies, and the design tried in between - an fp32
-//     pass plus an fp64 re-evaluation of the rare ill-conditioned bodies - costs MORE: the flagged wavefronts are the
-//     tail of every launch (+1.4 us on a 2.7 us launch of 4 096 bodies).
+//   * on this chip precision is not what an instruction costs: a wave-instruction takes ~4.2 cycles for fp64 arithmetic,
+//     2.7 for fp32 arithmetic and ~4 for everything else the body is made of (conversions, selects, bit operations;
+//     scripts/ubench_valu.hip), and a third of the body is of the last kind.  Measured: the all-fp64
+//     body costs about what the fp32 + fp64-island body it replaces cost at 1 M bodies, and the design tried in between -
+//     an fp32 pass plus an fp64 re-evaluation of the rare ill-conditioned bodies - costs MORE: the flagged wavefronts are
+//     the tail of every launch (+1.4 us on a 2.7 us launch of 4 096 bodies).  What does pay is instruction COUNT (round 3:
+//     520 -> 460 VALU per body, see solve_body): the kernels are co-limited by HBM and VALU issue at the clock the chip
+//     holds under both.
 // No MFMA: the path is elementwise per body.
 //
 // The model (what must come out) is the reference's
