@@ -356,9 +356,12 @@ class AosReplica:
         self._prepared(self.dt)
 
 
-def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 13):
+def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 8, seed: int = 13):
     """The simulator-facing entry (hydro_step_wrench_aos: (N,3)/(N,4)/(N,6) tensors in, forces/torques
-    out, previous velocity kept in the engine): 168 algorithmic bytes per body-step, all of them real traffic."""
+    out, previous velocity kept in the engine): 168 algorithmic bytes per body-step, all of them real traffic.
+    EIGHT rotating sets: the kernel reads the simulator's rows (52 B per body) with temporal loads, and four sets of them
+    (218 MB) would sit in the 256 MiB Infinity Cache while everything else streams past - a cache rate (26.5 instead of
+    29.8 us at 1 M bodies), not the HBM rate this entry is quoted at."""
     sc = build_scene("c4", n, seed)
     reps = [AosReplica(sc, "f32", dev, roll=r * 97) for r in range(sets)]
     spin_up(reps, stream, 0.15)
@@ -369,6 +372,7 @@ def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 4, seed: int = 1
     gbs = sc.n * 168 / (us * 1e-6) / 1e9
     return {"n": sc.n, "entry_point": "hydro_step_wrench_aos", "us_per_step": us, "body_steps_per_s": sc.n / (us * 1e-6),
             "algorithmic_gbs": gbs, "bytes_per_body_step": 168, "frac": gbs / HBM_PEAK_GBS,
+            "rotating_sets": sets, "temporal_bytes_rotating": sets * sc.n * 52,
             **residency(sc.n, "f32", sets, 12 + 16 + 24 + 24 + 24 + 44)}
 
 
@@ -767,6 +771,8 @@ def main():
     else:
         sc = build_scene(kind, n, seed=5 + rank)
     cls = AosReplica if args.layout == "aos" else Replica
+    if args.layout == "aos" and args.scenes * (args.bodies or n_default) * 52 < (410 << 20):
+        args.scenes = max(args.scenes, -(-(410 << 20) // ((args.bodies or n_default) * 52)))     # (see aos_rate: no resident rows)
     replicas = [cls(sc, coeff, dev, roll=r * 131071, layout=args.layout) for r in range(args.scenes)]
     if args.bodies_per_lane:
         for r in replicas:

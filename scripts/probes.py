@@ -200,7 +200,9 @@ def clock_probes(n: int, dev, stream, seconds: float = 2.0) -> dict:
 
 def _aos_case(sc, n, sets, dev, L, sp):
     """The array-of-structs entry (fp32 parameters, engine-owned previous velocity) beside memory-only probes of its
-    168 B/body in both access shapes."""
+    168 B/body in both access shapes.  Enough rotating sets that the simulator's rows (52 B per body, read with temporal
+    loads) cannot stay in the Infinity Cache between two uses."""
+    sets = max(sets, -(-(410 << 20) // (n * 52)))
     from silver2_isaacsim_amd.engine import HydroEngine
     tiles = n // 64
     engines, tens, args = [], [], []
@@ -221,7 +223,7 @@ def _aos_case(sc, n, sets, dev, L, sp):
         "memory-only: AoS traffic, 16-byte chunks per wave": lambda r: L.probe_launch_aos(1, ctypes.byref(args[r % sets]), sp),
         "memory-only: AoS traffic, one row per lane": lambda r: L.probe_launch_aos(0, ctypes.byref(args[r % sets]), sp),
         "kernel: hydro_step_wrench_aos (fp32 parameters)": lambda r: steps[r % sets](sc.dt),
-    }
+    }                                   # (`sets` here is this function's own, possibly larger, count)
     return {"cases": cases, "engines": engines, "keep": tens}
 
 

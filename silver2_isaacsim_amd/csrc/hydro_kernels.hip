@@ -689,10 +689,19 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
     if (i >= n) return;
     const uint32_t tile = i >> 6, lane = i & 63u;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-    const f3_a4 p = ld_f3_a4<NT>(k_pos, i * 12u);
-    const f4_a16 q = ld_f4_a16<NT>(k_quat, i * 16u);
-    const f4_a8 v0 = ld_f4_a8<NT>(k_vel, i * 24u);
-    const f2_a8 v1 = ld_f2_a8<NT>(k_vel, i * 24u + 16u);
+    // The simulator's rows are read with TEMPORAL loads whatever the size: the simulator has just written them, so they
+    // are the one input that can still be in L2 / the Infinity Cache (the engine's own records and the outputs stream).
+    // Measured (A/B, -DHYDRO_AB_AOS_ROWS_NT=1 for the streaming arm): equal when nothing can be resident (8 rotating sets
+    // of 1 M bodies: 29.84 vs 29.96 us; 4 M: 112.2 vs 112.3), 12 % faster when the rows are (4 sets: 26.5 vs 30.2 us) -
+    // which is also why bench.py rotates EIGHT sets for this entry: its figure must be an HBM rate.
+#ifndef HYDRO_AB_AOS_ROWS_NT
+#define HYDRO_AB_AOS_ROWS_NT 0
+#endif
+    constexpr bool RNT = NT && (HYDRO_AB_AOS_ROWS_NT != 0);
+    const f3_a4 p = ld_f3_a4<RNT>(k_pos, i * 12u);
+    const f4_a16 q = ld_f4_a16<RNT>(k_quat, i * 16u);
+    const f4_a8 v0 = ld_f4_a8<RNT>(k_vel, i * 24u);
+    const f2_a8 v1 = ld_f2_a8<RNT>(k_vel, i * 24u + 16u);
     s[0] = p.x; s[1] = p.y; s[2] = p.z;
     if (quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
     else           { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
@@ -999,15 +1008,29 @@ struct IntArgs {
 //     m (v' - v)/dt = (F - k_lin v) + k_lin v' + m g     =>   v' = (m v + dt (F - k_lin v + m g)) / (m - dt k_lin)
 // and likewise per principal axis for the angular part.  Unconditionally stable in the drag terms -
 // the explicit form needs |k| dt / m < 2, which the 0.45 kg SILVER2 links at 120 Hz violate (5.5).
+// 1/x and 1/sqrt(x) in fp32: the hardware seed (1 ulp) and one Newton step (~0.5 ulp) - 3 and 4 instructions where the
+// IEEE-exact division and sqrt + division expand to ~10 and ~20.  The integrator stands in for PhysX in closed-loop runs
+// (SURVEY.md 8f row 2): it has no reference to be bit-exact with.
+__device__ __forceinline__ float rcp_nr(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float rsqrt_nr(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x * r, r, 1.0f), 0.5f * r, r);
+}
+
 template <bool IMPLICIT>
 __device__ __forceinline__ void integrate_body(const float (&s)[HYDRO_STATE_FIELDS], const float (&f)[HYDRO_WRENCH_FIELDS],
                                                float m, float dx, float dy, float dz, float g, float dt,
                                                float k_lin, float k_ang, float (&o)[HYDRO_STATE_FIELDS])
 {
-    const float inv_m = 1.0f / m;
+    const float inv_m = rcp_nr(m);
     float vx, vy, vz;
     if constexpr (IMPLICIT) {
-        const float den = 1.0f / (m - dt * k_lin);
+        const float den = rcp_nr(m - dt * k_lin);
         vx = (m * s[7] + dt * (f[0] - k_lin * s[7])) * den;
         vy = (m * s[8] + dt * (f[1] - k_lin * s[8])) * den;
         vz = (m * s[9] + dt * (f[2] - k_lin * s[9] - m * g)) * den;
@@ -1034,13 +1057,13 @@ __device__ __forceinline__ void integrate_body(const float (&s)[HYDRO_STATE_FIEL
     const float tbz = r02 * f[3] + r12 * f[4] + r22 * f[5];
     float nbx, nby, nbz;
     if constexpr (IMPLICIT) {
-        nbx = (ix * wbx + dt * (tbx - k_ang * wbx - (wby * (iz * wbz) - wbz * (iy * wby)))) / (ix - dt * k_ang);
-        nby = (iy * wby + dt * (tby - k_ang * wby - (wbz * (ix * wbx) - wbx * (iz * wbz)))) / (iy - dt * k_ang);
-        nbz = (iz * wbz + dt * (tbz - k_ang * wbz - (wbx * (iy * wby) - wby * (ix * wbx)))) / (iz - dt * k_ang);
+        nbx = (ix * wbx + dt * (tbx - k_ang * wbx - (wby * (iz * wbz) - wbz * (iy * wby)))) * rcp_nr(ix - dt * k_ang);
+        nby = (iy * wby + dt * (tby - k_ang * wby - (wbz * (ix * wbx) - wbx * (iz * wbz)))) * rcp_nr(iy - dt * k_ang);
+        nbz = (iz * wbz + dt * (tbz - k_ang * wbz - (wbx * (iy * wby) - wby * (ix * wbx)))) * rcp_nr(iz - dt * k_ang);
     } else {
-        nbx = wbx + dt * (tbx - (wby * (iz * wbz) - wbz * (iy * wby))) / ix;
-        nby = wby + dt * (tby - (wbz * (ix * wbx) - wbx * (iz * wbz))) / iy;
-        nbz = wbz + dt * (tbz - (wbx * (iy * wby) - wby * (ix * wbx))) / iz;
+        nbx = wbx + dt * (tbx - (wby * (iz * wbz) - wbz * (iy * wby))) * rcp_nr(ix);
+        nby = wby + dt * (tby - (wbz * (ix * wbx) - wbx * (iz * wbz))) * rcp_nr(iy);
+        nbz = wbz + dt * (tbz - (wbx * (iy * wby) - wby * (ix * wbx))) * rcp_nr(iz);
     }
     const float wx = r00 * nbx + r01 * nby + r02 * nbz;
     const float wy = r10 * nbx + r11 * nby + r12 * nbz;
@@ -1051,7 +1074,7 @@ __device__ __forceinline__ void integrate_body(const float (&s)[HYDRO_STATE_FIEL
     float nqy = qy + h * (wy * qw + wz * qx - wx * qz);
     float nqz = qz + h * (wz * qw + wx * qy - wy * qx);
     float nqw = qw - h * (wx * qx + wy * qy + wz * qz);
-    const float inv_n = 1.0f / sqrtf(nqx * nqx + nqy * nqy + nqz * nqz + nqw * nqw);
+    const float inv_n = rsqrt_nr(nqx * nqx + nqy * nqy + nqz * nqz + nqw * nqw);
     o[0] = px; o[1] = py; o[2] = pz;
     o[3] = nqx * inv_n; o[4] = nqy * inv_n; o[5] = nqz * inv_n; o[6] = nqw * inv_n;
     o[7] = vx; o[8] = vy; o[9] = vz;
