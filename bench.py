@@ -530,7 +530,8 @@ def bound_probes_leg(n: int, dev, stream):
     us = r["us"]
     pick = lambda key: next(v for k, v in us.items() if key in k)           # noqa: E731
     out = {"n": n,
-           "memory_only_us": pick("product pattern"), "compute_only_us": pick("lane-generated"),
+           "memory_only_us": pick("product pattern, write-through"), "memory_only_nt_stores_us": pick("product pattern (4-byte"),
+           "compute_only_us": pick("lane-generated"),
            "compute_l2_resident_inputs_us": pick("L2-resident"), "kernel_us": pick("hydro_step_wrench_tiled"),
            "aos_memory_only_us": pick("AoS traffic, one row per lane"), "aos_memory_only_chunked_us": pick("AoS traffic, 16-byte"),
            "aos_kernel_us": pick("hydro_step_wrench_aos"),

@@ -41,6 +41,28 @@ __global__ void __launch_bounds__(256) probe_dword(const PArgs a)
     for (int f = 0; f < 6; ++f) stnt(o + f * 64, acc + (float)f);
 }
 
+// P0w: the same with WRITE-THROUGH stores (sc0 sc1), the policy the product's streaming stores use since round 3
+__global__ void __launch_bounds__(256) probe_dword_wt(const PArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
+    if (tile >= a.tiles) return;
+    const float* s = a.st + (size_t)tile * 832 + lane; const float* p = a.pv + (size_t)tile * 384 + lane;
+    const float* q = a.prm + (size_t)tile * 480 + lane;
+    const unsigned short* hq = reinterpret_cast<const unsigned short*>(a.prm + (size_t)tile * 480 + 256) + lane;
+    float acc = 0.0f;
+#pragma unroll
+    for (int f = 2; f < 13; ++f) acc += ldnt(s + f * 64);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) acc += ldnt(p + f * 64);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc += ldnt(q + f * 64);
+#pragma unroll
+    for (int f = 0; f < 7; ++f) acc += (float)ldnt(hq + f * 64);
+    float* o = a.out + (size_t)tile * 384 + lane;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) __hip_atomic_store(o + f * 64, acc + (float)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // P1: the same bytes as sixteen-byte accesses (what an LDS-transposed kernel would issue): 2.75 + 1.5 + 1.875 loads
 // and 1.5 stores per lane.  STORE = false: the read-only ceiling of this shape.
 template <bool STORE>
@@ -283,6 +305,7 @@ extern "C" int probe_launch(int which, const PArgs* a, const void* src, void* ds
         case 4: hipLaunchKernelGGL(probe_compute<0>, grid, blk, 0, s, *a, 1025.0, 9.81, 60.0); break;
         case 5: hipLaunchKernelGGL(probe_compute<1>, grid, blk, 0, s, *a, 1025.0, 9.81, 60.0); break;
         case 6: hipLaunchKernelGGL(probe_ke, grid, blk, 0, s, *a); break;
+        case 7: hipLaunchKernelGGL(probe_dword_wt, grid, blk, 0, s, *a); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -51,7 +51,8 @@ class AArgs(ctypes.Structure):
 
 NAMES = {0: "memory-only: product pattern (4-byte loads/stores)", 1: "memory-only: same bytes, 16-byte loads/stores",
          2: "memory-only: same reads, 16-byte, no stores", 3: "float4 copy 1:1, same total bytes",
-         4: "compute-only: lane-generated inputs", 5: "compute-only: 64 L2-resident tiles", 6: "memory-only: KE reads (56 B/body)"}
+         4: "compute-only: lane-generated inputs", 5: "compute-only: 64 L2-resident tiles", 6: "memory-only: KE reads (56 B/body)",
+         7: "memory-only: product pattern, write-through stores"}
 
 _lib = None
 
@@ -112,7 +113,7 @@ def _time(fn, stream, reps: int, warm: int = 20) -> float:
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def bound_probes(n: int, dev, stream, rounds: int = 5, which=(0, 4, 5), with_aos: bool = True, with_ke: bool = True,
+def bound_probes(n: int, dev, stream, rounds: int = 5, which=(0, 7, 4, 5), with_aos: bool = True, with_ke: bool = True,
                  reps: int | None = None) -> dict:
     """{memory-only, compute-only, kernel} microseconds per launch at n bodies, interleaved round by round (medians).
     Headline kernel = hydro_step_wrench_tiled, fp16 coefficients, rotating replicas as bench.py steps them."""
@@ -234,7 +235,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0"); stream = torch.cuda.Stream(dev)
     log = open(os.path.join(OUT, "probes.log"), "a")
     for n in [int(x) for x in sys.argv[1:]] or [1048576, 4194304]:
-        r = bound_probes(n, dev, stream, rounds=7, which=(0, 1, 2, 4, 5))
+        r = bound_probes(n, dev, stream, rounds=7, which=(0, 7, 1, 2, 4, 5))
         for name, us in r["us"].items():
             line = f"n={n:9d} {name:58s}: {us:8.2f} us"
             print(line, flush=True); log.write(line + "\n")

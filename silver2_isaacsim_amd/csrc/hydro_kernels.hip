@@ -96,19 +96,77 @@ __device__ __forceinline__ T* at(void* __restrict__ p, uint32_t lane_off, uint32
     return reinterpret_cast<T*>(static_cast<char*>(p) + lane_off + field_off);
 }
 
-// NT = non-temporal (streaming) access: every byte of a large scene is touched once per step,
-// so nothing is worth keeping in L2 / Infinity Cache; measured +5..9 % on the SoA kernel.
+// NT = streaming access: every byte of a large scene is touched once per step, so nothing is worth keeping in
+// L2 / Infinity Cache: non-temporal loads (measured +5..9 % on the SoA kernel) and write-through stores (below).
 template <bool NT, typename V>
 __device__ __forceinline__ V ldg(const V* p)
 {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
+// Streaming STORES are write-through (`sc0 sc1`), not `nt`.  An nt store leaves its line dirty in the XCD's L2 to be
+// written back later (MI355X_MICROARCH.md: "plain / sc0 / nt KEEP the line in L2, sc1 / sc0 sc1 DROP it"); a kernel
+// that writes 24-48 B per body and never reads them again does better handing them straight to the memory side.
+// Measured, sustained over 2 s per variant on two boxes (scripts/ab_sustained.py, C5): nt 22.83-23.09 / 23.5-25.1 us,
+// sc1 21.44 / 22.8-24.0, sc0 sc1 21.36 / 22.15-22.5 us per launch (-6.5 %); 4 M bodies 80.9 -> 79.0 us; identical bits.
+// A/B knob: -DHYDRO_AB_STORE_POLICY=0 (nt) / 1 (sc1) / 2 (sc0 sc1, default).
+#ifndef HYDRO_AB_STORE_POLICY
+#define HYDRO_AB_STORE_POLICY 2
+#endif
+#ifndef HYDRO_AB_WIDE_STORE_WT        // A/B knob: 12- and 16-byte streaming stores write-through too (1, default) or nt (0)
+#define HYDRO_AB_WIDE_STORE_WT 1
+#endif
+// One write-through store of 4, 8, 12 or 16 bytes.  The compiler offers the cache policy only through atomics (4 and 8
+// bytes); the wider ones are spelled out.  Nothing in a kernel reads these addresses back, so the store the compiler
+// cannot see needs no waitcnt of its own ("memory" keeps it ordered against the surrounding accesses).
+// BYTES is spelled out because sizeof() of a 3-vector is 16.
+template <int BYTES, typename V>
+__device__ __forceinline__ void store_write_through(void* p, V v)        // void*: the caller vouches for the alignment
+{
+#if HYDRO_AB_STORE_POLICY == 1
+    constexpr int scope = __HIP_MEMORY_SCOPE_AGENT;
+#else
+    constexpr int scope = __HIP_MEMORY_SCOPE_SYSTEM;
+#endif
+    if constexpr (BYTES == 4) {
+        __hip_atomic_store(static_cast<V*>(p), v, __ATOMIC_RELAXED, scope);
+    } else if constexpr (BYTES == 8) {
+        __hip_atomic_store(static_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, scope);
+    } else if constexpr (BYTES == 12 && HYDRO_AB_WIDE_STORE_WT) {
+#if HYDRO_AB_STORE_POLICY == 1
+        asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#else
+        asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#endif
+    } else if constexpr (BYTES == 16 && HYDRO_AB_WIDE_STORE_WT) {
+#if HYDRO_AB_STORE_POLICY == 1
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#else
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#endif
+    } else {
+        __builtin_nontemporal_store(v, static_cast<V*>(p));
+    }
+}
+// The simulator-facing AoS kernel is the exception: its 12-byte force / torque rows and its prev-velocity fields measured
+// 2-3 % FASTER as nt stores (27.75 vs 28.32 us at 1 M bodies, 102.0 vs 105.1 us at 4 M), so it stays on stg_nt.
 template <bool NT, typename V>
-__device__ __forceinline__ void stg(V* p, V v)
+__device__ __forceinline__ void stg_nt(V* p, V v)
 {
     if constexpr (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void stg(V* p, V v)
+{
+    if constexpr (NT) {
+#if HYDRO_AB_STORE_POLICY == 0
+        __builtin_nontemporal_store(v, p);
+#else
+        static_assert(sizeof(V) == 4 || sizeof(V) == 8 || (sizeof(V) == 16 && alignof(V) == 16), "3-vectors go through st_f3_a4");
+        store_write_through<(int)sizeof(V)>(p, v);
+#endif
+    } else *p = v;
 }
 
 template <int VEC, bool NT>
@@ -664,20 +722,29 @@ struct AosArgs {
 // up with conflict-free strides, three wavefront fences): 30.3 vs 34.0 us at 1 M bodies, 111.6 vs 113.7 us at 4 M,
 // identical bits; 91 % / 100 % of a memory-only probe of the same traffic (scripts/probes.py).
 // --------------------------------------------------------------------------
+#ifndef HYDRO_AB_AOS_STORE_WT         // A/B knob: write-through stores in the AoS kernel too (measured slower, see stg_nt)
+#define HYDRO_AB_AOS_STORE_WT 0
+#endif
+template <bool NT, typename V>
+__device__ __forceinline__ void stg_aos(V* p, V v)
+{
+    if constexpr (HYDRO_AB_AOS_STORE_WT) stg<NT>(p, v); else stg_nt<NT>(p, v);
+}
 typedef float f3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef float f4_a16 __attribute__((ext_vector_type(4), aligned(16)));
 // (one function per type: a template parameter would drop the typedef's alignment and let the compiler assume 16)
-#define HYDRO_WIDE_ACCESS(T)                                                                                              \
+#define HYDRO_WIDE_ACCESS(T, BYTES)                                                                                       \
     template <bool NT> __device__ __forceinline__ T ld_##T(const void* base, uint32_t byte_off)                              \
     { const T* q = reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off); if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; } \
     template <bool NT> __device__ __forceinline__ void st_##T(void* base, uint32_t byte_off, T v)                            \
-    { T* q = reinterpret_cast<T*>(static_cast<char*>(base) + byte_off); if constexpr (NT) __builtin_nontemporal_store(v, q); else *q = v; }
-HYDRO_WIDE_ACCESS(f3_a4)
-HYDRO_WIDE_ACCESS(f4_a8)
-HYDRO_WIDE_ACCESS(f2_a8)
-HYDRO_WIDE_ACCESS(f4_a16)
+    { T* q = reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);                                                      \
+      if constexpr (!NT) *q = v; else if constexpr (!HYDRO_AB_AOS_STORE_WT) __builtin_nontemporal_store(v, q); else store_write_through<BYTES>(q, v); }
+HYDRO_WIDE_ACCESS(f3_a4, 12)
+HYDRO_WIDE_ACCESS(f4_a8, 16)
+HYDRO_WIDE_ACCESS(f2_a8, 8)
+HYDRO_WIDE_ACCESS(f4_a16, 16)
 #undef HYDRO_WIDE_ACCESS
 
 template <bool HALF, bool NT, bool WARP>
@@ -727,7 +794,7 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
     }
     const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, WARP);
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(k_pv, po, f * 256u), s[7 + f]);
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg_aos<NT>(at<float>(k_pv, po, f * 256u), s[7 + f]);
     f3_a4 fo, to;
     fo.x = w.fx; fo.y = w.fy; fo.z = w.fz; to.x = w.tx; to.y = w.ty; to.z = w.tz;
     st_f3_a4<NT>(k_force, i * 12u, fo);
@@ -810,7 +877,7 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_kernel(const float* k_pos, 
 
     if (live) {
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv, po, f * 256u), s[7 + f]);
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg_aos<NT>(at<float>(a.pv, po, f * 256u), s[7 + f]);
     }
     wave_lds_fence();                                              // every lane has read its velocity
     lds[3 * lane] = w.fx; lds[3 * lane + 1] = w.fy; lds[3 * lane + 2] = w.fz;
