@@ -98,11 +98,21 @@ __device__ __forceinline__ T* at(void* __restrict__ p, uint32_t lane_off, uint32
 
 // NT = streaming access: every byte of a large scene is touched once per step, so nothing is worth keeping in
 // L2 / Infinity Cache: non-temporal loads (measured +5..9 % on the SoA kernel) and write-through stores (below).
+#ifndef HYDRO_AB_LOAD_POLICY          // A/B knob for the streaming loads: 0 = nt (default), 1 = sc1, 2 = sc0 sc1
+#define HYDRO_AB_LOAD_POLICY 0
+#endif
 template <bool NT, typename V>
 __device__ __forceinline__ V ldg(const V* p)
 {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
+    if constexpr (NT) {
+#if HYDRO_AB_LOAD_POLICY == 0
+        return __builtin_nontemporal_load(p);
+#else
+        constexpr int scope = HYDRO_AB_LOAD_POLICY == 1 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM;
+        if constexpr (sizeof(V) == 4 || sizeof(V) == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, scope);
+        else return __builtin_nontemporal_load(p);
+#endif
+    } else return *p;
 }
 // Streaming STORES are write-through (`sc0 sc1`), not `nt`.  An nt store leaves its line dirty in the XCD's L2 to be
 // written back later (MI355X_MICROARCH.md: "plain / sc0 / nt KEEP the line in L2, sc1 / sc0 sc1 DROP it"); a kernel
@@ -473,6 +483,95 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
         ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
     }
 }
+
+#ifndef HYDRO_AB_TILED_PIPE           // A/B arm: tiles per wave of the software-pipelined kernel below (0 = not used)
+#define HYDRO_AB_TILED_PIPE 0
+#endif
+#if HYDRO_AB_TILED_PIPE
+// --------------------------------------------------------------------------
+// A/B arm ("software pipelining"): every wave walks HYDRO_AB_TILED_PIPE tiles grid-stride and
+// issues the loads of its NEXT tile before it starts the arithmetic of the current one (two named register sets, so no
+// copies).  4 waves per SIMD leave 128 VGPRs per lane: ~95 for the arithmetic + 28 for the tile in flight.
+// --------------------------------------------------------------------------
+template <bool HALF, bool NT>
+struct TileRegs {
+    float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], mass, cf[7];
+    unsigned short ch[7];
+    __device__ __forceinline__ void load(const float* st, const float* pvp, const float* prm, uint32_t st_stride, uint32_t pv_stride, uint32_t tile, uint32_t lane)
+    {
+        const uint32_t so = (__umul24(tile, st_stride) + lane) * 4u, po = (__umul24(tile, pv_stride) + lane) * 4u;
+#pragma unroll
+        for (int f = 2; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(st, so, f * 256u));
+        s[0] = 0.0f; s[1] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(pvp, po, f * 256u));
+        if constexpr (HALF) {
+            const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(prm, qo, f * 256u));
+            mass = ldg<NT>(at<float>(prm, qo, 3 * 256u));
+            const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
+#pragma unroll
+            for (int f = 0; f < 7; ++f) ch[f] = ldg<NT>(at<unsigned short>(prm, ho, f * 128u));
+        } else {
+            const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(prm, qo, f * 256u));
+#pragma unroll
+            for (int f = 0; f < 7; ++f) cf[f] = ldg<NT>(at<float>(prm, qo + (3 + f) * 256u));
+            mass = ldg<NT>(at<float>(prm, qo, 10 * 256u));
+        }
+    }
+};
+
+template <bool HALF, bool WRITE_PREV, bool NT, bool WARP>
+#ifndef HYDRO_AB_PIPE_WAVES
+#define HYDRO_AB_PIPE_WAVES 3
+#endif
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HYDRO_AB_PIPE_WAVES, HYDRO_AB_PIPE_WAVES)))
+wrench_tiled_pipe_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
+                         uint32_t st_stride, uint32_t pv_stride, uint32_t out_stride, uint32_t pvo_stride,
+                         uint32_t n, uint32_t tiles, uint32_t wave_stride, uint32_t per_wave, double rho, double g, double inv_dt)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t t0 = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (t0 >= tiles) return;
+    auto process = [&](TileRegs<HALF, NT>& r, uint32_t tile) {
+        float c[7];
+#pragma unroll
+        for (int f = 0; f < 7; ++f) c[f] = HALF ? half_bits_to_float(r.ch[f]) : r.cf[f];
+        const hydro::Wrench w = body_wrench(r.s, r.pv, r.d, c, r.mass, rho, g, inv_dt, WARP);
+        if (tile < tiles && tile * 64u + lane < n) {
+            const uint32_t oo = (__umul24(tile, out_stride) + lane) * 4u;
+            stg<NT>(at<float>(k_out, oo), w.fx); stg<NT>(at<float>(k_out, oo, 256u), w.fy); stg<NT>(at<float>(k_out, oo, 512u), w.fz);
+            stg<NT>(at<float>(k_out, oo, 768u), w.tx); stg<NT>(at<float>(k_out, oo, 1024u), w.ty); stg<NT>(at<float>(k_out, oo, 1280u), w.tz);
+            if constexpr (WRITE_PREV) {
+                const uint32_t wo = (__umul24(tile, pvo_stride) + lane) * 4u;
+#pragma unroll
+                for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(k_pv_out, wo, f * 256u), r.s[7 + f]);
+            }
+        }
+    };
+    // Every wave walks exactly `per_wave` (even) tiles; a tile index past the end is clamped to the last tile (at most
+    // 4 x per_wave redundant tile reads per launch) and its stores are skipped.  No branch guards a load: a conditional
+    // prefetch makes the compiler's waitcnt for the CURRENT tile assume the prefetch was not issued, which drains it.
+    const uint32_t last = tiles - 1u;
+    TileRegs<HALF, NT> A, B;
+    A.load(k_st, k_pv, k_prm, st_stride, pv_stride, t0, lane);
+    for (uint32_t j = 2; j < per_wave; j += 2) {
+        const uint32_t t1 = t0 + wave_stride, t2 = t1 + wave_stride;
+        B.load(k_st, k_pv, k_prm, st_stride, pv_stride, t1 < last ? t1 : last, lane);
+        process(A, t0);
+        A.load(k_st, k_pv, k_prm, st_stride, pv_stride, t2 < last ? t2 : last, lane);
+        process(B, t1);
+        t0 = t2;
+    }
+    const uint32_t t1 = t0 + wave_stride;
+    B.load(k_st, k_pv, k_prm, st_stride, pv_stride, t1 < last ? t1 : last, lane);
+    process(A, t0);
+    process(B, t1);
+}
+#endif  // HYDRO_AB_TILED_PIPE
 
 #if HYDRO_AB_TILED_LDS
 // --------------------------------------------------------------------------
@@ -1824,7 +1923,24 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
         else { if (own_prev) HYDRO_TILED_KE(false, true); else HYDRO_TILED_KE(false, false); }
 #undef HYDRO_TILED_KE
 #undef HYDRO_TILED_KE_W
-    } else if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
+    }
+#if HYDRO_AB_TILED_PIPE
+    else if (n >= (int64_t)HYDRO_AB_TILED_PIPE * 1024 * HYDRO_AB_PIPE_WAVES * 64) {
+        const uint32_t tiles = (uint32_t)((n + 63) / 64);
+        uint32_t pblocks = (tiles + 4u * HYDRO_AB_TILED_PIPE - 1u) / (4u * HYDRO_AB_TILED_PIPE);
+        const uint32_t wstride = pblocks * 4u;
+#define HYDRO_PIPE_LAUNCH(HALF, WP, NT, W) hipLaunchKernelGGL((wrench_tiled_pipe_kernel<HALF, WP, NT, W>), dim3(pblocks), dim3(kBlock), 0, s, \
+        a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, tiles, wstride, (uint32_t)HYDRO_AB_TILED_PIPE, a.rho, a.g, a.inv_dt)
+#define HYDRO_PIPE_W(HALF, WP, NT) do { if (a.warp) HYDRO_PIPE_LAUNCH(HALF, WP, NT, true); else HYDRO_PIPE_LAUNCH(HALF, WP, NT, false); } while (0)
+#define HYDRO_PIPE_NT(HALF, WP) do { if (nt) HYDRO_PIPE_W(HALF, WP, true); else HYDRO_PIPE_W(HALF, WP, false); } while (0)
+        if (h->half_coeffs) { if (own_prev) HYDRO_PIPE_NT(true, true); else HYDRO_PIPE_NT(true, false); }
+        else { if (own_prev) HYDRO_PIPE_NT(false, true); else HYDRO_PIPE_NT(false, false); }
+#undef HYDRO_PIPE_NT
+#undef HYDRO_PIPE_W
+#undef HYDRO_PIPE_LAUNCH
+    }
+#endif
+    else if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
 #endif
 #undef HYDRO_TILED_HALF
 #undef HYDRO_TILED_WP
