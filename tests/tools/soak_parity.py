@@ -86,5 +86,5 @@ summ = {"bodies_checked": total["bodies"], "bin_edges": edges[:-1] + ["inf"], "h
         "kinetic_energy_samples_checked_vs_fp64_host_sum_1e-12": ke_checks[0],
         "runs": per}
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(summ, open(os.path.join(REPO, "gpurun_out", os.environ.get("HYDRO_SOAK_OUT", "parity_soak.json")), "w"), indent=1)
+json.dump(summ, open(os.path.join(REPO, "gpurun_out", os.path.basename(os.environ.get("HYDRO_SOAK_OUT", "parity_soak.json"))), "w"), indent=1)
 print(json.dumps({k: v for k, v in summ.items() if k != "runs"}, indent=1))
