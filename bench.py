@@ -842,6 +842,7 @@ def main():
                          **residency(sc.n, coeff, args.scenes)},
             "spinup_seconds": args.spinup_seconds,
             "collectives": (f"{'nccl (RCCL)' if hd.collective_device(dev).type == 'cuda' else 'gloo'}, {world} rank(s)" if multi else "none (single process)"),
+            "barrier": hd.barrier_kind(),
             "global_kinetic_energy_J": [float(x) for x in ke.cpu().tolist()],
             "ke_allreduce_us": ke_us,
         }

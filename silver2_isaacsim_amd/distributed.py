@@ -51,7 +51,10 @@ def init_process_group(backend: str | None = None, device_id: int | None = None,
         torch.cuda.set_device(dev)
         kw["device_id"] = torch.device("cuda", dev)
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    return True
+    global _node_barrier
+    _node_barrier = False           # (a new group: a barrier of an earlier one is not its barrier)
+    _setup_node_barrier()           # here, not at the first barrier(): its set-up takes milliseconds of host time, and a
+    return True                     # GPU left idle that long right before a timed region starts it at a lower clock
 
 
 def collective_device(default: torch.device | str) -> torch.device:
@@ -93,6 +96,93 @@ def global_kinetic_energy(local_ke: torch.Tensor, async_op: bool = False):
     return local_ke, work
 
 
+class NodeBarrier:
+    """Barrier for the ranks of ONE host through a shared-memory page: rank r is the only writer of slot r (one cache
+    line each), a barrier is "publish my epoch, spin until every slot has reached it".  The ranks of a bench run sit on
+    one node by contract; a dist.barrier() over RCCL is an all-reduce launch plus a stream synchronisation (tens of
+    microseconds), which is a tenth of a 20-step timed region - this one costs about a microsecond, and its ranks
+    leave it within a microsecond of each other, which is what the max-over-ranks wall time wants.  Built collectively
+    (every rank calls NodeBarrier.create at the same point); None when the ranks span hosts."""
+
+    LINE = 8                                              # int64 per slot = one 64-byte line
+
+    def __init__(self, rank: int, world: int, mm):
+        import numpy as np
+        self.rank, self.world, self._mm = rank, world, mm
+        self.slots = np.frombuffer(mm, dtype=np.int64, count=world * self.LINE).reshape(world, self.LINE)
+        self.epoch = 0
+
+    @classmethod
+    def create(cls) -> "NodeBarrier | None":
+        import mmap
+        import socket
+        rank, world = dist.get_rank(), dist.get_world_size()
+        try:
+            boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            boot = ""
+        ids = [None] * world
+        dist.all_gather_object(ids, (socket.gethostname(), boot))
+        if len(set(ids)) != 1 or not os.path.isdir("/dev/shm"):
+            return None
+        path = f"/dev/shm/hydro_barrier_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
+        size = max(4096, world * cls.LINE * 8)
+        if rank == 0:
+            fd = os.open(path, os.O_CREAT | os.O_TRUNC | os.O_RDWR, 0o600)
+            os.ftruncate(fd, size)                        # zero-filled
+        dist.barrier()                                    # the file exists with its final size
+        if rank != 0:
+            fd = os.open(path, os.O_RDWR)
+        mm = mmap.mmap(fd, size)
+        os.close(fd)
+        dist.barrier()                                    # everybody has it mapped
+        if rank == 0:
+            os.unlink(path)                               # the mappings keep the page; nothing is left behind
+        return cls(rank, world, mm)
+
+    def wait(self, timeout_s: float = 120.0) -> None:
+        import time
+        self.epoch += 1
+        e = self.epoch
+        self.slots[self.rank, 0] = e
+        col = self.slots[:, 0]
+        spins = 0
+        t_end = None
+        while int(col.min()) < e:
+            spins += 1
+            if spins & 0xFFFF == 0:                       # a rank that died must not hang the others for ever
+                now = time.monotonic()
+                if t_end is None:
+                    t_end = now + timeout_s
+                elif now > t_end:
+                    raise TimeoutError(f"node barrier: rank {self.rank} waited {timeout_s:.0f} s at epoch {e}: {col.tolist()}")
+
+
+_node_barrier: "NodeBarrier | None | bool" = False          # False = not tried yet
+
+
+def _setup_node_barrier() -> None:
+    global _node_barrier
+    if _node_barrier is False and dist.is_available() and dist.is_initialized():
+        _node_barrier = None if os.environ.get("HYDRO_BARRIER") == "dist" else NodeBarrier.create()
+
+
 def barrier():
-    if _collectives_on():
+    """Barrier over all ranks; no-op without a process group.  Ranks on one host use NodeBarrier (set up collectively by
+    init_process_group, or at the first call when the group was made elsewhere); HYDRO_BARRIER=dist, or ranks on several
+    hosts, fall back to torch.distributed's own."""
+    if not _collectives_on():
+        return
+    _setup_node_barrier()
+    if _node_barrier is None:
         dist.barrier()
+    else:
+        _node_barrier.wait()
+
+
+def barrier_kind() -> str:
+    if not _collectives_on():
+        return "none (single process)"
+    if _node_barrier is False:
+        return "not used yet"
+    return "torch.distributed.barrier" if _node_barrier is None else "node-local shared-memory epoch barrier"

@@ -19,9 +19,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, barrier_kind="node"):
     import sys
     sys.path.insert(0, REPO)
+    if barrier_kind == "dist":
+        os.environ["HYDRO_BARRIER"] = "dist"
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from silver2_isaacsim_amd import distributed as hd
@@ -43,15 +45,29 @@ def _worker(rank, world, port, q):
     tm = torch.tensor([1.0 + rank], dtype=torch.float64)
     hd.all_reduce_max_(tm)
     hd.barrier()
+    # the node-local barrier really orders the ranks: rank 1 dawdles before each of 50 barriers, rank 0 must not get ahead
+    import time
+    if barrier_kind == "dist":
+        assert hd.barrier_kind() == "torch.distributed.barrier"     # HYDRO_BARRIER=dist: the fallback ranks on several hosts take
+    else:
+        assert hd.barrier_kind() == "node-local shared-memory epoch barrier"
+        nb = hd._node_barrier
+        for k in range(50):
+            if rank == 1 and k % 10 == 0:
+                time.sleep(0.01)
+            hd.barrier()
+            assert int(nb.slots[:, 0].min()) >= nb.epoch and int(nb.slots[:, 0].max()) <= nb.epoch + 1
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("hydro_barrier_") and f.endswith(str(port))]
     q.put((rank, float(out[0]), ke_full, float(tm[0]), mine.n))
     dist.destroy_process_group()
 
 
-def test_world_size_2_shards_and_ke_allreduce():
+@pytest.mark.parametrize("barrier_kind", ["node", "dist"])
+def test_world_size_2_shards_and_ke_allreduce(barrier_kind):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, barrier_kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
