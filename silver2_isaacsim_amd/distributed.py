@@ -127,18 +127,34 @@ class NodeBarrier:
             return None
         path = f"/dev/shm/hydro_barrier_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
         size = max(4096, world * cls.LINE * 8)
-        if rank == 0:
-            fd = os.open(path, os.O_CREAT | os.O_TRUNC | os.O_RDWR, 0o600)
-            os.ftruncate(fd, size)                        # zero-filled
+        fd, mm, ok = -1, None, True
+        try:
+            if rank == 0:
+                fd = os.open(path, os.O_CREAT | os.O_TRUNC | os.O_RDWR, 0o600)
+                os.ftruncate(fd, size)                    # zero-filled
+        except OSError:
+            ok = False
         dist.barrier()                                    # the file exists with its final size
-        if rank != 0:
-            fd = os.open(path, os.O_RDWR)
-        mm = mmap.mmap(fd, size)
-        os.close(fd)
-        dist.barrier()                                    # everybody has it mapped
+        try:
+            if rank != 0:
+                fd = os.open(path, os.O_RDWR)
+            mm = mmap.mmap(fd, size)
+            os.close(fd)
+        except (OSError, ValueError):
+            ok = False
+        nb = cls(rank, world, mm) if ok else None
+        if nb is not None:
+            nb.slots[rank, 1] = rank + 1                  # self-test: is this page really the one the others see?
+        dist.barrier()                                    # everybody has it mapped and signed
         if rank == 0:
-            os.unlink(path)                               # the mappings keep the page; nothing is left behind
-        return cls(rank, world, mm)
+            try:
+                os.unlink(path)                           # the mappings keep the page; nothing is left behind
+            except OSError:
+                pass
+        seen = nb is not None and nb.slots[:, 1].tolist() == list(range(1, world + 1))
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(seen))
+        return nb if all(flags) else None                 # all ranks or none: a mixed choice would deadlock
 
     def wait(self, timeout_s: float = 120.0) -> None:
         import time
