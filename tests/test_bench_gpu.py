@@ -102,6 +102,7 @@ def test_bench_gpus_2_launches_its_own_ranks(native_built):
     assert len(lines) == 1 and lines[0].startswith("{")
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collectives"] == "gloo, 2 rank(s)" and "x2" in d["config"]["sharding"]
+    assert d["barrier"] == "node-local shared-memory epoch barrier"      # the ranks of one host time their region with it
     assert d["c4_strong"]["n_gpus"] == 2 and d["c4_strong"]["bodies_this_rank"] == 131072
 
 

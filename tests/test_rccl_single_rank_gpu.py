@@ -75,3 +75,4 @@ def test_bench_strong_leg_over_rccl(native_built):
     cs = d["c4_strong"]
     assert cs["bodies_this_rank"] == 262144 and cs["kinetic_energy"]["samples"] == 2 and cs["kinetic_energy"]["host_waits"] == 0
     assert d["collectives"] == "nccl (RCCL), 1 rank(s)"
+    assert d["barrier"] == "node-local shared-memory epoch barrier"      # built over the RCCL group's own collectives
