@@ -8,6 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "hydro_kernels.hip")
 DEPS = [SRC, os.path.join(_HERE, "csrc", "hydro_body.h"),
+        os.path.join(_HERE, "csrc", "hydro_ab_tiled_arms.h"), os.path.join(_HERE, "csrc", "hydro_ab_aos_arm.h"),
         os.path.join(os.path.dirname(_HERE), "include", "hydro.h")]
 OUT = os.path.join(_HERE, "lib", "libhydro.so")
 ARCH = "gfx950"
