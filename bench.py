@@ -376,15 +376,18 @@ def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 8, seed: int = 1
             **residency(sc.n, "f32", sets, 12 + 16 + 24 + 24 + 24 + 44)}
 
 
-def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, implicit_drag: bool = False):
+def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, implicit_drag: bool = False, resident: bool = False):
     """Wrench + integrator ping-pong replayed from a HIP graph (simulate.ClosedLoopSim); RTF as
     benchmark_rtf.py defines it (sim time / wall time).  fused: one kernel per physics step
-    (hydro_step_fused_tiled) instead of two."""
+    (hydro_step_fused_tiled) instead of two.  resident: one launch per 64 physics steps, the bodies carried through them
+    in registers (hydro_step_fused_tiled_multi; same bits) - no HBM traffic and no launch between the steps."""
     from silver2_isaacsim_amd.simulate import ClosedLoopSim
     sim = ClosedLoopSim(build_scene(kind, n, 17), fused=fused, implicit_drag=implicit_drag)
-    r = sim.measure_rtf(steps, graph_steps=64)
+    r = sim.measure_rtf(steps, graph_steps=64, resident=resident)
     sim.close()
     mode = "hipGraph x64 (hydro_step_fused_tiled)" if fused else "hipGraph x64 (wrench_tiled + integrate_tiled)"
+    if resident:
+        mode = "64 steps per launch, bodies resident in registers (hydro_step_fused_tiled_multi)"
     if implicit_drag:
         mode += ", implicit drag"
     # ONE scene stepping on itself: state ping-pong (2 x 52 B) + parameters
@@ -931,6 +934,10 @@ def main():
             guarded("closed_loop_c2_262144", closed_loop_rate, "c2", 262144, steps=1024)
             guarded("closed_loop_c2_262144_unfused", closed_loop_rate, "c2", 262144, steps=1024, fused=False)
             guarded("closed_loop_c2_1048576", closed_loop_rate, "c2", 1048576, steps=512)
+            guarded("closed_loop_c2_4096_resident", closed_loop_rate, "c2", 4096, resident=True)
+            guarded("closed_loop_c3_1024envs_implicit_resident", closed_loop_rate, "c3", 19456, implicit_drag=True, resident=True)
+            guarded("closed_loop_c2_262144_resident", closed_loop_rate, "c2", 262144, steps=1024, resident=True)
+            guarded("closed_loop_c2_1048576_resident", closed_loop_rate, "c2", 1048576, steps=512, resident=True)
             out["extras"] = ex
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -39,8 +39,9 @@ extern "C" {
 /* 0.2.0: scene scalars are doubles (hydro_set_scene), hydro_set_semantics, waves_per_simd in hydro_set_tuning
  * 0.3.0: dt is a double in every step / integrate entry point; the model is evaluated in fp64
  * 0.4.0: hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke (kinetic energy sampled inside the step kernel),
- *        hydro_reserve_soa; the engine holds 68 B per body and makes its plain-SoA copies on first use */
-#define HYDRO_VERSION 0x000400
+ *        hydro_reserve_soa; the engine holds 68 B per body and makes its plain-SoA copies on first use
+ * 0.5.0: hydro_step_fused_tiled_multi (any number of closed-loop steps in one pass, the bodies stay in registers) */
+#define HYDRO_VERSION 0x000500
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
@@ -242,6 +243,23 @@ int hydro_step_fused_tiled_ke(hydro_t *h, int64_t n, const float *state, int64_t
                               float *state_out, int64_t out_tile_stride,
                               float *wrench, int64_t wrench_tile_stride, int implicit_drag,
                               int rotational, double *ke_out_dev, void *stream);
+
+/* `steps` closed-loop steps in ONE pass over the tiled buffers.  No term of the model couples two bodies, so every body is
+ * carried through all the steps in registers: state, previous velocity and parameters are read once; `state_out` receives
+ * the state after the last step and `prev_out` (6 fields, tiled) the velocity of the step before it, i.e. what the next
+ * call needs as `prev`.  Same arithmetic in the same order, hence the same bits, as `steps` calls of
+ * hydro_step_fused_tiled - with (120 + 76) / steps bytes of traffic per body-step instead of 172 and one launch
+ * instead of `steps` (intermediate states never exist in memory: sample, log or couple at multiples of `steps`).
+ * Aliasing: `state_out` may alias the buffer `prev` points into, `prev_out` may alias `state` + 7 * 64 (the velocity
+ * fields of the state being read) - with both, the two-buffer ping-pong of the single-step entry carries over unchanged;
+ * `state_out` must not alias `state`.  ke_out_dev != NULL: also sample the kinetic energy of the final state (two doubles
+ * on the device, see hydro_step_wrench_tiled_ke).  1 <= steps <= 2^20.
+ * New functionality (the reference steps PhysX once per callback); SURVEY.md 8f row 2. */
+int hydro_step_fused_tiled_multi(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
+                                 const float *prev, int64_t prev_tile_stride, double dt, int steps,
+                                 float *state_out, int64_t out_tile_stride,
+                                 float *prev_out, int64_t prev_out_tile_stride, int implicit_drag,
+                                 int rotational, double *ke_out_dev, void *stream);
 
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
  * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1), resident waves per

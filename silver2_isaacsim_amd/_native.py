@@ -49,6 +49,8 @@ SIGNATURES = {
                                        c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "hydro_step_fused_tiled_ke": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                           c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "hydro_step_fused_tiled_multi": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double, c_int,
+                                             c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "hydro_reserve_soa": (c_int, [c_void_p]),
     "hydro_integrate_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                       c_void_p, c_int64, c_void_p]),

@@ -1046,6 +1046,59 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k
     if constexpr (KE) ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
 }
 
+// --------------------------------------------------------------------------
+// `steps` closed-loop steps in ONE pass: no term of the model couples two bodies, so a lane can carry its body through any
+// number of steps in registers - state, previous velocity and the 11 parameters are read once, the state after the last
+// step and the velocity of the step before it are written once.  Per body-step that is (120 + 76) / steps bytes instead
+// of 172, and one launch instead of `steps`: the loop is bound by the arithmetic alone (section 6 of DESIGN.md).
+// Same arithmetic, same order, hence the same bits as `steps` launches of step_fused_tiled_kernel.
+// k_pvo may alias the velocity fields of the state this kernel READS (each lane reads its own fields first): the
+// two-buffer ping-pong of the single-step entry then carries over unchanged.
+// --------------------------------------------------------------------------
+template <bool HALF, bool NT, bool IMPLICIT, bool KE, bool WARP>
+__global__ void __launch_bounds__(kBlock) step_fused_multi_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_so, float* k_pvo,
+                                                                       uint32_t st_stride, uint32_t pv_stride, uint32_t so_stride, uint32_t pvo_stride,
+                                                                       uint32_t n, uint32_t steps, float dt, double rho, double g, double inv_dt,
+                                                                       double* ke_partials, uint32_t ke_stride, int ke_rotational)
+{
+    TiledArgs a;
+    a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pvo; a.pvo_stride = pvo_stride;
+    a.prm = k_prm; a.out = nullptr; a.out_stride = 0; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = WARP; a.n = n;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if constexpr (!KE) {
+        if (i >= n) return;
+    }
+    double ke_lin = 0.0, ke_rot = 0.0;
+    if (!KE || i < n) {
+        const uint32_t tile = i >> 6, lane = i & 63u;
+        const uint32_t so = (__umul24(tile, st_stride) + lane) * 4u;
+        const uint32_t po = (__umul24(tile, pv_stride) + lane) * 4u;
+        float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
+        load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+#pragma unroll 1
+        for (uint32_t k = 0; k < steps; ++k) {
+            const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, WARP);
+            const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
+            float o[HYDRO_STATE_FIELDS];
+            integrate_body<IMPLICIT>(s, f6, mass, d[0], d[1], d[2], g, dt, w.k_lin, w.k_ang, o);
+#pragma unroll
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = s[7 + f];
+#pragma unroll
+            for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = o[f];
+        }
+        if constexpr (KE)
+            hydro::kinetic_energy(s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], d[0], d[1], d[2], mass,
+                                  ke_rotational != 0, ke_lin, ke_rot);
+        const uint32_t wo = (__umul24(tile, pvo_stride) + lane) * 4u;
+#pragma unroll
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(k_pvo, wo, f * 256u), pv[f]);
+        const uint32_t oo = (__umul24(tile, so_stride) + lane) * 4u;
+#pragma unroll
+        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(k_so, oo, f * 256u), s[f]);
+    }
+    if constexpr (KE) ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
+}
+
 }  // namespace
 
 // ==========================================================================
@@ -1787,6 +1840,45 @@ int hydro_step_fused_tiled_ke(hydro_t* h, int64_t n, const float* state, int64_t
     if (h && !ke_out_dev) return fail(h, HYDRO_E_ARG, "null ke_out_dev");
     return step_fused_tiled_impl(h, n, state, state_tile_stride, prev, prev_tile_stride, dt, state_out, out_tile_stride,
                                  wrench, wrench_tile_stride, implicit_drag, rotational ? 1 : 0, ke_out_dev, stream);
+}
+
+int hydro_step_fused_tiled_multi(hydro_t* h, int64_t n, const float* state, int64_t state_tile_stride,
+                                 const float* prev, int64_t prev_tile_stride, double dt, int steps,
+                                 float* state_out, int64_t out_tile_stride,
+                                 float* prev_out, int64_t prev_out_tile_stride, int implicit_drag,
+                                 int rotational, double* ke_out_dev, void* stream)
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (steps < 1 || steps > (1 << 20)) return fail(h, HYDRO_E_ARG, "steps must be in 1 .. 2^20");
+    if ((rc = check_tiled(h, n, state, state_tile_stride, HYDRO_STATE_FIELDS, "null state"))) return rc;
+    if ((rc = check_tiled(h, n, prev, prev_tile_stride, HYDRO_PREV_FIELDS, "null prev (pass the previous state buffer + 7*64)"))) return rc;
+    if ((rc = check_tiled(h, n, state_out, out_tile_stride, HYDRO_STATE_FIELDS, "null state_out"))) return rc;
+    if ((rc = check_tiled(h, n, prev_out, prev_out_tile_stride, HYDRO_PREV_FIELDS, "null prev_out (pass state + 7*64 to keep the two-buffer ping-pong)"))) return rc;
+    if (state_out == state) return fail(h, HYDRO_E_ARG, "state_out must not alias state (it may alias the previous-state buffer)");
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) return ke_out_dev ? ke_finish(h, 0, ke_out_dev, s) : HYDRO_OK;
+    const double inv_dt = 1.0 / dt;
+    const float dtf = (float)dt;
+    const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
+    const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
+    const int ke_rot = rotational ? 1 : 0;
+#define HYDRO_MULTI_ARGS state, prev, h->params_tiled, state_out, prev_out, (uint32_t)state_tile_stride, (uint32_t)prev_tile_stride, (uint32_t)out_tile_stride, \
+        (uint32_t)prev_out_tile_stride, (uint32_t)n, (uint32_t)steps, dtf, h->rho, h->g, inv_dt, h->ke_partials, h->ke_stride, ke_rot
+#define HYDRO_MULTI_W(HALF, NT, KE, WARP) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_multi_tiled_kernel<HALF, NT, true, KE, WARP>), grid, blk, 0, s, HYDRO_MULTI_ARGS); \
+                                               else hipLaunchKernelGGL((step_fused_multi_tiled_kernel<HALF, NT, false, KE, WARP>), grid, blk, 0, s, HYDRO_MULTI_ARGS); } while (0)
+#define HYDRO_MULTI_I(HALF, NT, KE) do { if (h->semantics) HYDRO_MULTI_W(HALF, NT, KE, true); else HYDRO_MULTI_W(HALF, NT, KE, false); } while (0)
+#define HYDRO_MULTI(HALF, NT) do { if (ke_out_dev) HYDRO_MULTI_I(HALF, NT, true); else HYDRO_MULTI_I(HALF, NT, false); } while (0)
+    if (h->half_coeffs) { if (nt) HYDRO_MULTI(true, true); else HYDRO_MULTI(true, false); }
+    else { if (nt) HYDRO_MULTI(false, true); else HYDRO_MULTI(false, false); }
+#undef HYDRO_MULTI
+#undef HYDRO_MULTI_I
+#undef HYDRO_MULTI_W
+#undef HYDRO_MULTI_ARGS
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return ke_out_dev ? ke_finish(h, n, ke_out_dev, s) : HYDRO_OK;
 }
 
 int hydro_pack_state_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,

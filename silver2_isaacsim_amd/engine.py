@@ -297,6 +297,28 @@ class HydroEngine:
                 ke_out.data_ptr(), self._stream(stream)))
         return state_out
 
+    def step_fused_tiled_multi(self, state: torch.Tensor, prev_state: torch.Tensor, n: int, dt: float, steps: int,
+                               state_out: torch.Tensor | None = None, implicit_drag: bool = False, stream=None,
+                               ke_out: torch.Tensor | None = None, rotational: bool = True):
+        """`steps` closed-loop steps in one kernel, every body carried through them in registers (same bits as `steps`
+        calls of step_fused_tiled).  Buffers as step_fused_tiled: `prev_state` supplies the previous velocity and, by
+        default, receives the final state; the velocity fields of `state` receive the velocity of the step before the
+        last one, so that after the call (state_out, state) are the (current, previous) pair of the next call.
+        ke_out: also sample the kinetic energy of the final state."""
+        self._check_tiled(state, nat.STATE_FIELDS, n)
+        self._check_tiled(prev_state, nat.STATE_FIELDS, n)
+        if state_out is None:
+            state_out = prev_state
+        self._check_tiled(state_out, nat.STATE_FIELDS, n)
+        if ke_out is not None:
+            self._check_ke_out(ke_out)
+        st, vel = nat.STATE_FIELDS * nat.TILE, 7 * nat.TILE * 4
+        self._check(self._lib.hydro_step_fused_tiled_multi(
+            self._h, n, state.data_ptr(), st, prev_state.data_ptr() + vel, st, float(dt), int(steps),
+            state_out.data_ptr(), st, state.data_ptr() + vel, st, int(bool(implicit_drag)), int(bool(rotational)),
+            ke_out.data_ptr() if ke_out is not None else None, self._stream(stream)))
+        return state_out
+
     def integrate_tiled(self, state_in: torch.Tensor, wrench: torch.Tensor, n: int, dt: float,
                         state_out: torch.Tensor | None = None, stream=None) -> torch.Tensor:
         if state_out is None:

@@ -232,6 +232,33 @@ class ClosedLoopSim:
         if steps:
             self.run_eager(steps)
 
+    def run_resident(self, steps: int, chunk: int = 64) -> None:
+        """Advance `steps` physics steps with the bodies RESIDENT IN REGISTERS: one hydro_step_fused_tiled_multi launch
+        per `chunk` steps (and one for the remainder).  The bodies are independent, so a launch reads every body once,
+        carries it through `chunk` steps and writes it once - no HBM traffic and no launch between the steps, same bits
+        as run_eager.  States between the ends of chunks never exist in memory: a kinetic-energy monitor samples at the
+        end of a chunk, so `ke_every` must be a multiple of `chunk` (and the run must start on such a boundary)."""
+        if not self.fused:
+            raise ValueError("the resident loop is the fused step")
+        if chunk < 1:
+            raise ValueError("chunk must be >= 1")
+        if self.monitor is not None and (self.monitor.every % chunk or self.steps_done % chunk):
+            raise ValueError(f"ke_every ({self.monitor.every}) must be a multiple of chunk ({chunk}) and the run must start "
+                             f"at one: the kinetic energy is sampled by the last step of a launch")
+        with torch.cuda.stream(self.stream):
+            while steps > 0:
+                k = min(chunk, steps)
+                sample = self.monitor is not None and k == chunk and (self.steps_done + k) % self.monitor.every == 0
+                if sample:
+                    self.monitor.wait_before_overwrite(self.stream)
+                self.engine.step_fused_tiled_multi(self.cur, self.old, self.n, self.dt, k, implicit_drag=self.implicit_drag,
+                                                   ke_out=self.ke_dev if sample else None)
+                self.cur, self.old = self.old, self.cur
+                self.steps_done += k
+                steps -= k
+                if sample:
+                    self.monitor.observe(self.steps_done, stream=self.stream, sampled=self.ke_dev)
+
     def synchronize(self) -> None:
         self.stream.synchronize()
 
@@ -246,12 +273,14 @@ class ClosedLoopSim:
         self.synchronize()
         return ke.cpu().numpy()
 
-    def measure_rtf(self, steps: int, graph_steps: int = 64) -> dict:
-        """Real-time factor the way benchmark_rtf.py:48-71 defines it: sim time / wall time."""
-        self.run(graph_steps or 2, graph_steps)         # capture + warm
+    def measure_rtf(self, steps: int, graph_steps: int = 64, resident: bool = False) -> dict:
+        """Real-time factor the way benchmark_rtf.py:48-71 defines it: sim time / wall time.
+        resident=True: run_resident with chunk = graph_steps instead of graph replays of single steps."""
+        go = (lambda k: self.run_resident(k, graph_steps or 64)) if resident else (lambda k: self.run(k, graph_steps))
+        go(graph_steps or 2)                            # capture + warm
         self.synchronize()
         t0 = time.perf_counter()
-        self.run(steps, graph_steps)
+        go(steps)
         self.synchronize()
         wall = time.perf_counter() - t0
         return {"physics_steps": steps, "wall_time_s": wall, "sim_time_s": steps * self.dt,

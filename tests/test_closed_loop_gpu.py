@@ -129,6 +129,10 @@ def test_silver2_envs_example(native_built):
     assert out["rtf"] > 10.0                                            # 120 Hz scene, microseconds per step
     ke0, ke1 = out["kinetic_energy_J"]["before"], out["kinetic_energy_J"]["after"]
     assert ke1[1] < ke0[1]                                              # the angular drag dissipates the initial spin
+    # 64 steps per launch, the links resident in registers: the same final state, bit for bit
+    res = demo.main(["--envs", "256", "--steps", "512", "--resident"])
+    assert res["resident"] and res["finite"] and res["kinetic_energy_J"]["after"] == ke1
+    assert (res["deepest_z"], res["highest_z"]) == (out["deepest_z"], out["highest_z"])
     # the same bodies through the plugin surface: one behavior instance per prim, one subscription, one launch per step
     via = demo.main(["--envs", "64", "--steps", "200", "--through-plugin"])
     assert via["bodies"] == 19 * 64 and via["physics_step_subscriptions"] == 1 and via["apply_calls"] == 300
@@ -156,6 +160,54 @@ def test_checkpoint_resume_is_bit_exact(native_built):
     got = c.state()
     c.close()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,coeff,implicit", [("c2", "f32", False), ("c2", "f16", False), ("c3", "f32", True), ("c5", "f16", True)])
+def test_resident_multi_step_launch_equals_single_steps(name, coeff, implicit, native_built):
+    """hydro_step_fused_tiled_multi: the bodies are independent, so one launch carries each of them through K steps in
+    registers.  Same arithmetic in the same order: the state after 1, 2, 7 and 64 + 64 + 9 resident steps has the BITS of
+    as many single-step launches, ragged size, explicit and implicit drag, and the two-buffer ping-pong (previous
+    velocity written into the buffer being read) hands the right previous velocity to the next launch."""
+    sc = {"c2": scenes.scene_c2, "c3": lambda n: scenes.scene_c3(envs=(n + 18) // 19), "c5": scenes.scene_c5}[name](3001)
+    a, b = ClosedLoopSim(sc, coeff_dtype=coeff, implicit_drag=implicit), ClosedLoopSim(sc, coeff_dtype=coeff, implicit_drag=implicit)
+    done = 0
+    for k, chunk in ((1, 1), (2, 2), (7, 7), (137, 64)):
+        a.run_eager(k)
+        b.run_resident(k, chunk=chunk)
+        done += k
+        sa, sb = a.state(), b.state()
+        assert a.steps_done == b.steps_done == done
+        # (the C5 population has light bodies no fixed-step integrator holds for 100+ steps: they diverge the same way)
+        assert (name == "c5" or np.isfinite(sa).all()) and np.array_equal(sa, sb, equal_nan=True), (name, k)
+        # ... and the buffer that holds "previous" carries the velocity of the step before (what the next launch reads)
+        assert np.array_equal(a.old[:, 7:13].cpu().numpy(), b.old[:, 7:13].cpu().numpy(), equal_nan=True)
+    # mixing the two entries mid-run changes nothing either
+    a.run(64, graph_steps=64); b.run_resident(32, chunk=32); b.run_eager(32)
+    assert np.array_equal(a.state(), b.state(), equal_nan=True)
+    with pytest.raises(ValueError):
+        ClosedLoopSim(sc, fused=False).run_resident(4)
+    a.close(); b.close()
+
+
+def test_resident_loop_samples_the_kinetic_energy_and_refuses_bad_calls(native_built):
+    sc = scenes.scene_c2(n=3000)
+    ref, res = ClosedLoopSim(sc, ke_every=64), ClosedLoopSim(sc, ke_every=64)
+    ref.run(192, graph_steps=64); res.run_resident(192, chunk=64)
+    ref.synchronize(); res.synchronize()
+    ref.monitor.collect(block=True); res.monitor.collect(block=True)
+    assert [s for s, _ in res.monitor.samples] == [64, 128, 192]
+    for (_, x), (_, y) in zip(ref.monitor.samples, res.monitor.samples):
+        assert x[0] == y[0] and x[1] == y[1]                      # same state bits, same fixed-order reduction
+    assert np.array_equal(ref.state(), res.state())
+    with pytest.raises(ValueError):
+        res.run_resident(60, chunk=48)                            # ke_every = 64 is not a multiple of 48
+    e = res.engine
+    from silver2_isaacsim_amd._native import HydroError
+    with pytest.raises(HydroError, match="steps must be"):
+        e.step_fused_tiled_multi(res.cur, res.old, sc.n, sc.dt, 0)
+    with pytest.raises(HydroError, match="must not alias"):
+        e.step_fused_tiled_multi(res.cur, res.old, sc.n, sc.dt, 4, state_out=res.cur)
+    ref.close(); res.close()
 
 
 def test_kinetic_energy_monitor_in_the_closed_loop(native_built):
