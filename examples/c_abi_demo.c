@@ -137,6 +137,28 @@ int main(int argc, char **argv)
                 if (!(hb[at] == hb[at]) || hb[at] > 1e30f || hb[at] < -1e30f) finite = 0;
             }
         if (!same || !finite) { fprintf(stderr, "graph replay and eager loop disagree (same=%d finite=%d)\n", same, finite); return 6; }
+        /* ... and the same 64 steps as ONE launch: the bodies are independent, hydro_step_fused_tiled_multi carries each of
+         * them through the steps in registers.  prev_out = the velocity fields of the state being read: after the call
+         * (c1, c0) are the (current, previous) pair, exactly as after one single step. */
+        {
+            float *c0, *c1;
+            CHECK_HIP(hipMalloc((void **)&c0, sbytes)); CHECK_HIP(hipMalloc((void **)&c1, sbytes));
+            CHECK_HIP(hipMemcpy(c0, t_state, sbytes, hipMemcpyDeviceToDevice));
+            CHECK_HIP(hipMemset(c1, 0, sbytes));
+            CHECK_HYDRO(h, hydro_step_fused_tiled_multi(h, n, c0, ss, c1 + 7 * HYDRO_TILE, ss, dt, K - 1, c1, ss, c0 + 7 * HYDRO_TILE, ss, 1, 1, NULL, stream));
+            CHECK_HYDRO(h, hydro_step_fused_tiled_multi(h, n, c1, ss, c0 + 7 * HYDRO_TILE, ss, dt, 1, c0, ss, c1 + 7 * HYDRO_TILE, ss, 1, 1, NULL, stream));
+            CHECK_HIP(hipStreamSynchronize(stream));
+            CHECK_HIP(hipMemcpy(hb, c0, sbytes, hipMemcpyDeviceToHost));       /* 63 + 1 steps: the newest state is in c0 */
+            for (int64_t i = 0; i < n; ++i)
+                for (int f = 0; f < 13; ++f) {
+                    const size_t at = (size_t)(i / HYDRO_TILE) * 13 * HYDRO_TILE + (size_t)f * HYDRO_TILE + (size_t)(i % HYDRO_TILE);
+                    if (memcmp(&ha[at], &hb[at], sizeof(float)) != 0) same = 0;
+                }
+            if (!same) { fprintf(stderr, "resident multi-step launch and eager loop disagree\n"); return 7; }
+            if (hydro_step_fused_tiled_multi(h, n, c0, ss, c1 + 7 * HYDRO_TILE, ss, dt, 0, c1, ss, c0 + 7 * HYDRO_TILE, ss, 1, 1, NULL, stream) != HYDRO_E_ARG) return 7;
+            fprintf(stderr, "resident loop: 63 + 1 steps in two launches, bit-identical to the eager loop\n");
+            CHECK_HIP(hipFree(c0)); CHECK_HIP(hipFree(c1));
+        }
         hipEvent_t e0, e1; float ms = 0.0f;
         CHECK_HIP(hipEventCreate(&e0)); CHECK_HIP(hipEventCreate(&e1));
         CHECK_HIP(hipEventRecord(e0, stream));

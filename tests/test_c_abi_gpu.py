@@ -41,6 +41,7 @@ def test_plain_c_host_program(tmp_path, native_built):
     err = ho.wrench_error(got[:, :3], got[:, 3:], fx["net_force"][:n], fx["net_torque"][:n], fx["params"][:n], rho, g)
     assert err.max() <= 1e-5
     assert "bit-identical to the eager loop" in run.stderr                         # 64 fused steps from a HIP graph, from C
+    assert "resident loop: 63 + 1 steps in two launches, bit-identical" in run.stderr  # hydro_step_fused_tiled_multi from C
     ke_line = [l for l in run.stderr.splitlines() if l.startswith("kinetic energy")][0]
     lin = float(ke_line.split()[2])
     assert lin == pytest.approx(ho.kinetic_energy(fx["state"][:n], fx["params"][:n])[0], rel=1e-8)
