@@ -129,7 +129,8 @@ class Replica:
     def step(self):
         if self.layout == "tiled":
             if self._prepared is None:                 # arguments validated once; bound to the stream current now
-                self._prepared = self.engine.prepare_step_wrench_tiled(self.state, self.n, self.dt, out=self.out, prev=self.prev)
+                own = os.environ.get("HYDRO_BENCH_OWN_PREV") == "1"     # dev: the engine-owned previous velocity (updated in place)
+                self._prepared = self.engine.prepare_step_wrench_tiled(self.state, self.n, self.dt, out=self.out, prev=None if own else self.prev)
             self._prepared()
         else:
             self.engine.step_wrench(self.state, self.dt, out=self.out, prev=self.prev)

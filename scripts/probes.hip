@@ -224,10 +224,11 @@ extern "C" int probe_launch_clock(int kind, const PArgs* a, void* stamps, void* 
 // forces 12 + torques 12 out.  WIDE: the simulator tensors as whole 16-byte chunks per wave (what the LDS-staged
 // kernel issues: 48 + 64 + 32 + 64 lanes); otherwise one 12- / 16- / 24-byte row per lane (dwordx3 / x4 / x4+x2).
 // ---------------------------------------------------------------------------------------------------------------
-struct AArgs { const float* pos; const float* quat; const float* vel; float* force; float* torque; float* pv; const float* prm; uint32_t n; };
+struct AArgs { const float* pos; const float* quat; const float* vel; float* force; float* torque; float* pv; const float* prm; uint32_t n;
+               float* pvo; };       // pvo: where the previous velocity is WRITTEN (== pv: in place, as the product does)
 using f2 = float __attribute__((ext_vector_type(2)));
 using f3 = float __attribute__((ext_vector_type(3)));
-template <bool WIDE>
+template <bool WIDE, bool PV_WT = false>
 __global__ void __launch_bounds__(256) probe_aos(const AArgs a)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
@@ -255,8 +256,12 @@ __global__ void __launch_bounds__(256) probe_aos(const AArgs a)
     for (int f = 0; f < 6; ++f) acc += ldnt(pv + f * 64);
 #pragma unroll
     for (int f = 0; f < 11; ++f) acc += ldnt(prm + f * 64);
+    float* pvo = a.pvo + (size_t)tile * 384 + lane;
 #pragma unroll
-    for (int f = 0; f < 6; ++f) stnt(pv + f * 64, acc + (float)f);
+    for (int f = 0; f < 6; ++f) {
+        if constexpr (PV_WT) __hip_atomic_store(pvo + f * 64, acc + (float)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else stnt(pvo + f * 64, acc + (float)f);
+    }
     if constexpr (WIDE) {
         f4 o; o.x = acc; o.y = acc + 1.0f; o.z = acc + 2.0f; o.w = acc + 3.0f;
         if (lane < 48u) {
@@ -288,8 +293,9 @@ extern "C" int probe_launch_aos(int wide, const AArgs* a, void* stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((a->n + 255) / 256), blk(256);
-    if (wide) hipLaunchKernelGGL(probe_aos<true>, grid, blk, 0, s, *a);
-    else hipLaunchKernelGGL(probe_aos<false>, grid, blk, 0, s, *a);
+    if (wide & 2) hipLaunchKernelGGL((probe_aos<false, true>), grid, blk, 0, s, *a);      // previous velocity written through
+    else if (wide & 1) hipLaunchKernelGGL((probe_aos<true>), grid, blk, 0, s, *a);
+    else hipLaunchKernelGGL((probe_aos<false>), grid, blk, 0, s, *a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -46,7 +46,8 @@ class PArgs(ctypes.Structure):
 
 class AArgs(ctypes.Structure):
     _fields_ = [("pos", ctypes.c_void_p), ("quat", ctypes.c_void_p), ("vel", ctypes.c_void_p), ("force", ctypes.c_void_p),
-                ("torque", ctypes.c_void_p), ("pv", ctypes.c_void_p), ("prm", ctypes.c_void_p), ("n", ctypes.c_uint32)]
+                ("torque", ctypes.c_void_p), ("pv", ctypes.c_void_p), ("prm", ctypes.c_void_p), ("n", ctypes.c_uint32),
+                ("pvo", ctypes.c_void_p)]
 
 
 NAMES = {0: "memory-only: product pattern (4-byte loads/stores)", 1: "memory-only: same bytes, 16-byte loads/stores",
@@ -218,7 +219,8 @@ def _aos_case(sc, n, sets, dev, L, sp):
         f, t = torch.empty((sc.n, 3), device=dev), torch.empty((sc.n, 3), device=dev)
         pv, prm = torch.rand(tiles * 384, device=dev), torch.rand(tiles * 704, device=dev)
         engines.append(e); tens.append((pos, quat, vel, f, t, pv, prm))
-        args.append(AArgs(pos.data_ptr(), quat.data_ptr(), vel.data_ptr(), f.data_ptr(), t.data_ptr(), pv.data_ptr(), prm.data_ptr(), n))
+        args.append(AArgs(pos.data_ptr(), quat.data_ptr(), vel.data_ptr(), f.data_ptr(), t.data_ptr(), pv.data_ptr(), prm.data_ptr(), n,
+                          pv.data_ptr()))
     steps = [engines[r].prepare_step_wrench_aos(*tens[r][:3], forces=tens[r][3], torques=tens[r][4]) for r in range(sets)]
     cases = {
         "memory-only: AoS traffic, 16-byte chunks per wave": lambda r: L.probe_launch_aos(1, ctypes.byref(args[r % sets]), sp),
