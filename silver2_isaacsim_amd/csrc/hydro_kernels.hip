@@ -37,6 +37,9 @@
 #ifndef HYDRO_AB_TILED_LDS            // A/B knob: hydro_step_wrench_tiled through wrench_tiled_lds_kernel (LDS-DMA staging)
 #define HYDRO_AB_TILED_LDS 0
 #endif
+#ifndef HYDRO_AB_XCD_REMAP            // A/B knob: contiguous eighths of the tiles per XCD in wrench_tiled_kernel (measured: see DESIGN.md)
+#define HYDRO_AB_XCD_REMAP 0
+#endif
 #ifndef HYDRO_AB_TILED_WAVES         // A/B knob: minimum resident waves per SIMD asked of the tiled wrench kernel (0 = what it needs)
 #define HYDRO_AB_TILED_WAVES 0
 #endif
@@ -437,7 +440,16 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pv_out; a.pvo_stride = pvo_stride;
     a.prm = k_prm; a.out = k_out; a.out_stride = out_stride; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = warp; a.n = n;
+#if HYDRO_AB_XCD_REMAP
+    // A/B arm: blocks are handed to the 8 XCDs round-robin; give XCD x the x-th contiguous eighth of
+    // the tiles instead of every eighth block.  Nothing is shared between blocks, so this only changes which DRAM pages the
+    // eight L2s stream from at a given moment.
+    const uint32_t per_xcd = (gridDim.x + 7u) >> 3;
+    const uint32_t bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t i = (bid < gridDim.x ? bid : blockIdx.x) * BLOCK + threadIdx.x;       // (exact when gridDim.x % 8 == 0, as in the A/B)
+#else
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+#endif
     if constexpr (!KE) {
         if (i >= a.n) return;
     }
