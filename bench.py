@@ -852,7 +852,9 @@ def main():
         }
         if traffic:
             out["roofline"]["traffic_source"] = traffic.get("source")
-        if traffic and not args.no_live_traffic and args.layout == "tiled":
+        if traffic and not args.no_live_traffic and args.layout == "tiled" and world > 1:
+            out["roofline"]["traffic_live_skipped"] = "multi-rank run: the counters are read in the N = 1 run (the committed passes are used here)"
+        elif traffic and not args.no_live_traffic and args.layout == "tiled":
             live, why_not = measure_traffic_live()
             if live is None:
                 out["roofline"]["traffic_live_skipped"] = why_not
