@@ -262,7 +262,7 @@ int hydro_step_fused_tiled_multi(hydro_t *h, int64_t n, const float *state, int6
                                  int rotational, double *ke_out_dev, void *stream);
 
 /* Kernel-variant selection for tuning: bodies per lane (0 = default, 1, 2), threads per block
- * (0 = chosen by size, 128, 256), non-temporal accesses (-1 = chosen by size, 0, 1), resident waves per
+ * (0 = chosen by size, 128, 256), streaming accesses - non-temporal loads, write-through stores - (-1 = chosen by size, 0, 1), resident waves per
  * SIMD of the tiled wrench kernel (-1 = chosen by size, 0 = whatever the registers allow, 1..8 = cap,
  * enforced with a dynamic-LDS request: the kernel itself uses no LDS). */
 int hydro_set_tuning(hydro_t *h, int bodies_per_lane, int block_threads, int non_temporal, int waves_per_simd);

@@ -2,16 +2,17 @@
 //
 // Every kernel is elementwise per rigid body: about 460 VALU instructions, two thirds of them fp64 (hydro_body.h says
 // why), against 122-144 B per body-step - no MFMA anywhere.  The wrench kernels are CO-LIMITED: a memory-only probe of
-// the traffic takes 21.7 us and a compute-only probe of the arithmetic 16 us at 1 M bodies, each at the ~2.4 GHz the chip
+// the traffic takes 20.5 us and a compute-only probe of the arithmetic 16 us at 1 M bodies, each at the ~2.4 GHz the chip
 // holds for it alone; doing both it holds ~2.0 GHz, where the arithmetic takes as long as the bytes (scripts/probes.py,
-// DESIGN.md section 6; kernel 22.4-23.6 us).  What matters is
+// DESIGN.md section 6; kernel 21.4 us).  What matters is
 //   * layouts in which each wave-instruction reads one contiguous 256-B run of one field
 //     (plain SoA) and - better - in which the ~28 runs a wavefront needs form three contiguous
 //     records (tiled SoA, the native layout): DRAM pages are consumed whole;
 //   * all of a body's 28 loads issued before the first use, so a wave has its whole working
 //     set in flight at once (single-pass kernels, latency hidden by 4-5 waves per SIMD: 95-108 VGPRs);
 //   * instruction count: every VALU instruction but fp32 arithmetic costs ~4 cycles per wave here, fp64 or not;
-//   * non-temporal accesses for scenes larger than the caches: every byte is touched once per step;
+//   * streaming accesses for scenes larger than the caches (every byte is touched once per step): non-temporal loads,
+//     and WRITE-THROUGH stores - an nt store parks its dirty line in L2, a write-through one hands it on (see stg);
 //   * nothing re-read and nothing written but the wrench (24 B per body).
 // The array-of-structs entry (the simulator's tensor layout) reads and writes one row per lane with 12- and 16-byte
 // accesses (LDS staging of the transposition was measured and lost: DESIGN.md section 5); the kinetic-energy
