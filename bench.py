@@ -289,6 +289,49 @@ def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets
             "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9, **residency(sc.n, coeff, sets)}
 
 
+def two_stream_rate(kind: str, n: int, coeff: str, dev, steps: int = 400, sets: int = 4, seed: int = 11):
+    """NOT the headline protocol: the rotating replicas are independent scenes; stepped round-robin on TWO streams (even /
+    odd replicas) the drain of one launch overlaps the ramp of the next.  The difference to the one-stream figure of the
+    same run is what ramp and drain cost a launch; per-kernel durations of overlapping launches
+    are meaningless, so this entry reports throughput only (HIP events from the first launch to the join of both streams)."""
+    sc = build_scene(kind, n, seed)
+    S = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    one = [Replica(sc, coeff, dev, roll=r * 97) for r in range(sets)]
+    two = [Replica(sc, coeff, dev, roll=r * 97) for r in range(sets)]
+    with torch.cuda.stream(S[0]):                       # (a prepared launch is bound to the stream current at its first call)
+        for r in one:
+            r.step()
+    for k, r in enumerate(two):
+        with torch.cuda.stream(S[k % 2]):
+            r.step()
+    spin_up(one, S[0], 0.15)
+    us = {}
+    for mode, reps in (("one_stream", one), ("two_streams", two)):
+        samples = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            e0, e1, ej = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+            for timed in (False, True):
+                if timed:
+                    e0.record(S[0])
+                    S[1].wait_event(e0)
+                for k in range(steps if timed else steps // 4):
+                    reps[k % sets].step()               # (bound to its stream above: no stream context per launch)
+            ej.record(S[1]); S[0].wait_event(ej)
+            e1.record(S[0]); e1.synchronize()
+            samples.append(e0.elapsed_time(e1) * 1e3 / steps)
+        us[mode] = float(np.median(samples))
+    for r in one + two:
+        r.engine.close()
+    gbs = sc.n * BYTES_PER_BODY[coeff] / (us["two_streams"] * 1e-6) / 1e9
+    return {"n": sc.n, "coeff": coeff, "us_per_step_one_stream": us["one_stream"], "us_per_step_two_streams": us["two_streams"],
+            "ramp_and_drain_us_per_launch": us["one_stream"] - us["two_streams"],
+            "body_steps_per_s_two_streams": sc.n / (us["two_streams"] * 1e-6), "algorithmic_gbs_two_streams": gbs,
+            "frac_two_streams": gbs / HBM_PEAK_GBS,
+            "note": "throughput of independent scenes on two streams; the headline, its roofline object and the profiles stay one stream, one launch at a time",
+            **residency(sc.n, coeff, sets)}
+
+
 def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int = 64, replays: int = 40, seed: int = 11):
     """Launch-bound small scenes: capture `steps_per_graph` consecutive steps (round-robin over 4
     scene replicas) into one HIP graph and replay it - one host call per 64 physics steps instead
@@ -923,6 +966,8 @@ def main():
             guarded("c5_f32_1048576", quick_rate, "c4", 1048576, "f32", dev, stream, steps=100)
             guarded("f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2)
             guarded("f16_4194304", quick_rate, "c5", 4194304, "f16", dev, stream, steps=50, sets=2)
+            guarded("two_streams_c5_1048576", two_stream_rate, "c5", 1048576, "f16", dev)
+            guarded("two_streams_f16_4194304", two_stream_rate, "c5", 4194304, "f16", dev, steps=100, sets=2)
             guarded("plain_soa_c5_1048576", quick_rate, "c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
             guarded("plain_soa_f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2, layout="soa")
             guarded("aos_entry_1048576", aos_rate, 1048576, dev, stream)
