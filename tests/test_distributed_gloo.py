@@ -81,6 +81,36 @@ def test_world_size_2_shards_and_ke_allreduce(barrier_kind):
         assert tmax == 2.0
 
 
+def _deserter(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from silver2_isaacsim_amd import distributed as hd
+    assert hd.init_process_group(backend="gloo")
+    hd.barrier()
+    if rank == 1:                                   # leaves without reaching the next barrier
+        q.put((rank, "left"))
+        return
+    try:
+        hd._node_barrier.wait(timeout_s=1.0)
+        q.put((rank, "passed"))
+    except TimeoutError as e:
+        q.put((rank, f"timeout: {e}"))
+
+
+def test_node_barrier_times_out_instead_of_hanging_when_a_rank_is_gone():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deserter, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[1] == "left" and res[0].startswith("timeout: node barrier: rank 0 waited 1 s at epoch 2")
+
+
 def test_single_process_helpers_are_noops():
     from silver2_isaacsim_amd import distributed as hd
     t = torch.tensor([3.0], dtype=torch.float64)
