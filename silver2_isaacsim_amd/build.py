@@ -28,23 +28,28 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+def device_flags() -> list[str]:
+    """Code-generation flags of the product library (also used by tests/test_isa_budget.py to read the assembly)."""
+    return ["-O3", f"--offload-arch={ARCH}", "-std=c++17",
+            # the SLP vectoriser packs the scalar fp32 math into v_pk_* pairs at the price of ~115
+            # v_mov and +24 VGPRs per lane (103 -> 79 without it): occupancy matters more here
+            "-fno-slp-vectorize",
+            # FMA contraction per source expression only (the HIP default, "fast", contracts across
+            # statements and does so differently in each template instantiation): every kernel
+            # variant, SoA or AoS, 1 or 2 bodies per lane, then returns the same bits for a body
+            "-ffp-contract=on",
+            # kernarg preload (gfx950): the first 16 dwords of a kernel's scalar arguments arrive in SGPRs with the wave
+            # instead of behind scalar-memory loads; the hot kernels order their arguments for it (hydro_kernels.hip)
+            "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
     """Compile csrc/hydro_kernels.hip -> lib/libhydro.so.  Returns the library path."""
     if not force and not is_stale():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc_path(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
-           # the SLP vectoriser packs the scalar fp32 math into v_pk_* pairs at the price of ~115
-           # v_mov and +24 VGPRs per lane (103 -> 79 without it): occupancy matters more here
-           "-fno-slp-vectorize",
-           # FMA contraction per source expression only (the HIP default, "fast", contracts across
-           # statements and does so differently in each template instantiation): every kernel
-           # variant, SoA or AoS, 1 or 2 bodies per lane, then returns the same bits for a body
-           "-ffp-contract=on",
-           # kernarg preload (gfx950): the first 16 dwords of a kernel's scalar arguments arrive in SGPRs with the wave
-           # instead of behind scalar-memory loads; the hot kernels order their arguments for it (hydro_kernels.hip)
-           "-mllvm", "-amdgpu-kernarg-preload-count=16"] + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
+    cmd = [hipcc_path()] + device_flags() + ["-fPIC", "-shared", "-Wall", "-Wno-unused-function"] \
+        + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))

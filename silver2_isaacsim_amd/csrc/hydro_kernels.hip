@@ -9,7 +9,7 @@
 //     (plain SoA) and - better - in which the ~28 runs a wavefront needs form three contiguous
 //     records (tiled SoA, the native layout): DRAM pages are consumed whole;
 //   * all of a body's 28 loads issued before the first use, so a wave has its whole working
-//     set in flight at once (single-pass kernels, latency hidden by 4-5 waves per SIMD: 95-108 VGPRs);
+//     set in flight at once (single-pass kernels, latency hidden by 4 waves per SIMD: 101-115 VGPRs);
 //   * instruction count: every VALU instruction but fp32 arithmetic costs ~4 cycles per wave here, fp64 or not;
 //   * streaming accesses for scenes larger than the caches (every byte is touched once per step): non-temporal loads,
 //     and WRITE-THROUGH stores - an nt store parks its dirty line in L2, a write-through one hands it on (see stg);
