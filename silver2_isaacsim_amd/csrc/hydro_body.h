@@ -243,11 +243,19 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
             wetmask = shift_in_sign(wetmask, zij[j] + ez);
         }
     }
+    // "Fully in by bounds" (:87-88): with NO keypoint above the surface the reference returns cob = position before it
+    // looks at the wet points - which matters when the top keypoint is EXACTLY on the surface (z = 0 is not wet, :80):
+    // 18/24/26 points are wet then and their mean is not the centre.  Decided on the top lattice value in the
+    // association the mask was built with - it IS one of the 27 values whose sign bits were taken - so the branch and
+    // the mask cannot disagree.  (The Warp twin has no such return: its cob is the mean of the wet points whenever there
+    // are any, warp_hydrodynamics.py:59-61.)
+    const double ztop = ((pz + fabs(ex)) + fabs(ey)) + fabs(ez);
+    const uint32_t cobmask = (warp || ztop > 0.0) ? wetmask : 0u;
     const int cnt = __builtin_popcount(wetmask);
-    const int s_i = __builtin_popcount(wetmask & lattice_mask(0, 2)) - __builtin_popcount(wetmask & lattice_mask(0, 0));
-    const int s_j = __builtin_popcount(wetmask & lattice_mask(1, 2)) - __builtin_popcount(wetmask & lattice_mask(1, 0));
-    const int s_k = __builtin_popcount(wetmask & lattice_mask(2, 2)) - __builtin_popcount(wetmask & lattice_mask(2, 0));
-    // fully in: all 27 wet, the index sums vanish by symmetry, cob = position; dry: nothing wet, sums 0, count 0 -> 1
+    const int s_i = __builtin_popcount(cobmask & lattice_mask(0, 2)) - __builtin_popcount(cobmask & lattice_mask(0, 0));
+    const int s_j = __builtin_popcount(cobmask & lattice_mask(1, 2)) - __builtin_popcount(cobmask & lattice_mask(1, 0));
+    const int s_k = __builtin_popcount(cobmask & lattice_mask(2, 2)) - __builtin_popcount(cobmask & lattice_mask(2, 0));
+    // fully in or dry: index sums 0, cob = position (the count of a dry body is 0 -> 1)
     const double inv_cnt = rcp64((double)(cnt > 1 ? cnt : 1));
     const double lbx = hx * ((double)s_i * inv_cnt), lby = hy * ((double)s_j * inv_cnt), lbz = hz * ((double)s_k * inv_cnt);
     o.armb_x = r00 * lbx + r01 * lby + r02 * lbz;

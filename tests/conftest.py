@@ -47,4 +47,4 @@ def native_built():
     return REPO
 
 
-SCENE_FIXTURES = ["c2", "c3", "c4", "c5", "c4_adversarial"]
+SCENE_FIXTURES = ["c2", "c3", "c4", "c5", "c4_adversarial", "ties"]

@@ -318,9 +318,37 @@ def save_c1_trajectory():
           f"rest branch fired {len(rest_steps)}x -> {os.path.getsize(path)} B")
 
 
+def save_ties():
+    """Exact surface ties (tests/populations.py surface_ties): quantised bodies whose top / bottom keypoint, centre or
+    a face centre has z = 0 EXACTLY, under cube rotations (fp32 sqrt(1/2) quarter turns, (1/2,1/2,1/2,1/2) thirds) and
+    non-unit quaternions - the inputs on which `pz < 0` (numba_hydrodynamics.py:80), `z_min >= 0` / `z_max <= 0`
+    (:86-87), `alignment > 0` (:132) and `norm(axis) < 1e-6` (:210) are decided on exact numbers.  Plus the one body
+    of VERDICT r3 (unit cube, p_z = -1/2, quarter turn about x) as row 0."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import populations
+    state, prev, params, kind = populations.surface_ties()
+    s = np.float32(np.sqrt(0.5))
+    state[0] = [0, 0, -0.5, s, 0, 0, s, 0.3, -0.1, 0.5, 0.2, 0.1, -0.4]
+    prev[0] = 0.0
+    params[0] = [1, 1, 1, 1.2, 0.8, 300.0, 150.0, 1.0, 0.05, 0.02, 500.0]
+    rho, g, dt = populations.RHO, populations.G, populations.DT
+    accel = (state[:, 7:13].astype(np.float64) - prev.astype(np.float64)) / np.float64(dt)
+    comps, ratio, rest = reference_batch(state, accel, params, rho, g)
+    net_f, net_t = reference_behavior_batch(state, prev, params, rho, g, dt)
+    path = os.path.join(HERE, "ties.npz")
+    np.savez_compressed(path, state=state, prev=prev, params=params, kind=kind.astype(np.int8), rho=np.float64(rho), g=np.float64(g),
+                        dt=np.float64(dt), components=comps, ratio=ratio, rest_completed=rest, net_force=net_f, net_torque=net_t)
+    print(f"ties: {len(state)} bodies, rest-completed {int(rest.sum())}, dry {int((ratio == 0).sum())}, full {int((ratio == 1).sum())}; "
+          f"{populations.tie_census(state, params)} -> {os.path.getsize(path)} B")
+    print(f"  row 0 (VERDICT r3 body): net_T {net_t[0]}  cob {comps[0, 6]}")
+
+
 def main():
     from silver2_isaacsim_amd import scenes
+    if "--only-ties" in sys.argv:
+        return save_ties()
     save_known_answers()
+    save_ties()
     sc = scenes.scene_c2()
     save_scene_fixture("c2", sc, np.arange(sc.n))
     sc = scenes.scene_c3()

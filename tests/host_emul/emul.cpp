@@ -51,3 +51,20 @@ extern "C" int emul_body(const float* s, const float* pv, const float* pr, doubl
     out[24] = c.ratio;
     return 0;
 }
+
+// component mode as components_kernel / components_aos_kernel evaluate it: explicit fp32 accelerations, scale 1
+// (hydro_step_components[_aos]); out = (n, 8, 3) in the reference's order, ratio = (n)
+extern "C" int emul_components(int64_t n, const float* state, const float* accel, const float* params, double rho64, double g64,
+                               float* out, float* ratio)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float* a = accel + 6 * i;
+        const hydro::BodyIn b = body_in(state + 13 * i, params + 11 * i);
+        const hydro::Body o = hydro::solve_body(b, a[0], a[1], a[2], a[3], a[4], a[5], 1.0, rho64, g64, g_warp != 0);
+        const hydro::Components c = hydro::round_components(o, b, g_warp != 0);
+        for (int k = 0; k < 8; ++k)
+            for (int x = 0; x < 3; ++x) out[24 * i + 3 * k + x] = c.v[k][x];
+        ratio[i] = c.ratio;
+    }
+    return 0;
+}

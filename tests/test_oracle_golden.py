@@ -20,12 +20,20 @@ def _rel(got, ref, floor=1e-12):
     return (np.linalg.norm(got - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), floor)).max()
 
 
+def _floor(name):
+    """Denominator floor of the relative error.  On the quantised `ties` bodies a term that is mathematically 0 (lift with
+    the velocity in the plane of the up vector: sin(2 asin d) with d = 0 up to rounding) comes out as 5e-15 N from the
+    reference and as exactly 0 from another summation order: rounding noise of a term whose neighbours are O(100) N is
+    compared absolutely there (1e-12 N)."""
+    return 1.0 if name == "ties" else 1e-12
+
+
 @pytest.mark.parametrize("name", ["kat"] + SCENE_FIXTURES)
 def test_numpy_oracle_matches_reference_outputs(name):
     fx = load_golden(name)
     out = ho.solve_components(fx["state"], accel_of(fx), fx["params"], float(fx["rho"]), float(fx["g"]))
     for i, field in enumerate(ho.COMPONENT_FIELDS):
-        assert _rel(out[field], fx["components"][:, i, :]) < TOL, field
+        assert _rel(out[field], fx["components"][:, i, :], _floor(name)) < TOL, field
     assert np.abs(out["ratio"] - fx["ratio"]).max() < 1e-15 + 1e-12
     if "rest_completed" in fx:
         assert np.array_equal(out["rest"], fx["rest_completed"])
@@ -35,7 +43,7 @@ def test_numpy_oracle_matches_reference_outputs(name):
 def test_c_oracle_matches_reference_outputs(name, native_built):
     fx = load_golden(name)
     comps, ratio = c_oracle.components(fx["state"], accel_of(fx), fx["params"], float(fx["rho"]), float(fx["g"]))
-    assert _rel(comps, fx["components"]) < TOL
+    assert _rel(comps, fx["components"], _floor(name)) < TOL
     assert np.abs(ratio - fx["ratio"]).max() < 1e-12
 
 

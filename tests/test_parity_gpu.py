@@ -716,17 +716,86 @@ def test_non_unit_quaternions_are_used_as_given(scale, native_built):
     assert np.percentile(err, 99.9) < 3e-6 and (err > GATE).sum() == 0
 
 
-def test_degenerate_inputs(native_built):
-    """Zero dimensions / mass / speed, faces exactly on the surface, -0.0, clamp, 10 km offsets."""
-    import edge_cases as ec
-    f, t = run_ext(ec.STATE, ec.PREV, ec.PARAMS, ec.RHO, ec.G, ec.DT)
-    ec.check(f, t)
-    eng = HydroEngine(len(ec.STATE), DEV, ec.RHO, ec.G)
-    eng.set_params(ec.PARAMS)
-    out = eng.step_wrench_tiled(tiled(ec.STATE), len(ec.STATE), ec.DT, prev=tiled(ec.PREV))
-    o = scenes.from_tiled(out.cpu().numpy(), len(ec.STATE))
-    assert np.array_equal(o[:, :3], f) and np.array_equal(o[:, 3:], t)
+def _components_both_entries(state, accel32, params, rho, g, coeff="f32"):
+    """(n,8,3) + ratio from hydro_step_components (plain SoA) and from hydro_step_components_aos: they must agree bit for bit."""
+    n = len(state)
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(params, coeff)
+    comps, ratio = eng.step_components(soa(state), soa(accel32))
+    c1 = comps.cpu().numpy().T.reshape(n, 8, 3)
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV)    # noqa: E731
+    out = torch.empty((8, n, 3), dtype=torch.float32, device=DEV)
+    r2 = torch.empty((n,), dtype=torch.float32, device=DEV)
+    eng.step_components_aos(dev(state[:, 0:3]), dev(state[:, 3:7]), dev(state[:, 7:10]), dev(state[:, 10:13]),
+                            dev(accel32[:, 0:3]), dev(accel32[:, 3:6]), out, r2)
+    torch.cuda.synchronize()
+    c2 = out.cpu().numpy().transpose(1, 0, 2)
+    assert np.array_equal(c1, c2) and torch.equal(ratio, r2)
     eng.close()
+    return c1, ratio.cpu().numpy()
+
+
+def _every_wrench_entry(state, prev, params, rho, g, dt):
+    """The net wrench from hydro_step_wrench_ext (1 and 2 bodies per lane), _tiled and _aos (both quaternion orders):
+    one set of bits."""
+    f, t = run_ext(state, prev, params, rho, g, dt)
+    f2, t2 = run_ext(state, prev, params, rho, g, dt, vec=2)
+    assert np.array_equal(f, f2) and np.array_equal(t, t2)
+    n = len(state)
+    eng = HydroEngine(n, DEV, rho, g)
+    eng.set_params(params)
+    o = scenes.from_tiled(eng.step_wrench_tiled(tiled(state), n, dt, prev=tiled(prev)).cpu().numpy(), n)
+    assert np.array_equal(o[:, :3], f) and np.array_equal(o[:, 3:], t)
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV)    # noqa: E731
+    for xyzw in (False, True):
+        eng.set_prev_velocity(prev)
+        q = state[:, 3:7] if xyzw else state[:, [6, 3, 4, 5]]
+        F, T = eng.step_wrench_aos(dev(state[:, 0:3]), dev(q), dev(state[:, 7:13]), dt, quat_xyzw=xyzw)
+        assert np.array_equal(F.cpu().numpy(), f) and np.array_equal(T.cpu().numpy(), t)
+    eng.close()
+    return f, t
+
+
+def test_degenerate_inputs(native_built):
+    """Zero dimensions / mass / speed, -0.0, clamp, 10 km offsets, and every surface tie of the model (top / bottom /
+    centre / face centre at z = 0, zero alignments, |axis| = 0) under four orientations - through every wrench entry and
+    both component entries (tests/edge_cases.py; the table a mean-of-wet-points CoB fails)."""
+    import edge_cases as ec
+    f, t = _every_wrench_entry(ec.STATE, ec.PREV, ec.PARAMS, ec.RHO, ec.G, ec.DT)
+    comps, ratio = _components_both_entries(ec.STATE, ec.ACCEL32, ec.PARAMS, ec.RHO, ec.G)
+    ec.check(f, t, None, comps, ratio)
+
+
+def test_surface_ties_through_every_entry(native_built):
+    """tests/golden/ties.npz - 4 096 quantised bodies with keypoints / face centres EXACTLY on the surface under cube
+    rotations and non-unit quaternions, outputs by the reference itself: net wrench within the gate through
+    hydro_step_wrench_ext, _tiled and _aos, and the calculator surface through hydro_step_components and _aos (forces to
+    1e-6 of the body's largest term, centres to half an fp32 ulp, cob = position exactly when the top keypoint is on the
+    surface: numba_hydrodynamics.py:87-88)."""
+    from test_numerics_host import check_components
+    fx = load_golden("ties")
+    rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])
+    f, t = _every_wrench_entry(fx["state"], fx["prev"], fx["params"], rho, g, dt)
+    err = ho.wrench_error(f, t, fx["net_force"], fx["net_torque"], fx["params"], rho, g)
+    assert err.max() <= GATE, f"{err.max():.3e} ({(err > GATE).sum()} bodies)"
+    assert abs(t[0, 0] - (-533.9520915)) < 1e-3                        # the body of VERDICT r3 (+94.5 before the fix)
+    dry = fx["ratio"] == 0.0
+    assert dry.sum() > 1000 and np.all(f[dry] == 0.0) and np.all(t[dry] == 0.0)
+    acc32 = accel_of(fx).astype(np.float32)
+    comps, ratio = _components_both_entries(fx["state"], acc32, fx["params"], rho, g)
+    ref = ho.solve_components(fx["state"], acc32.astype(np.float64), fx["params"].astype(np.float64), rho, g)
+    check_components(comps, ratio, ref)
+    for k in (6, 7):                                                    # centres straight against the reference's numbers
+        want = fx["components"][:, k, :]
+        tol = 0.5 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) * (1 + 1e-6) + 1e-12
+        assert np.all(np.abs(comps[:, k, :] - want) <= tol)
+    top_tie = (fx["kind"] == 1) & (fx["ratio"] == 1.0)
+    assert top_tie.sum() > 400 and np.array_equal(comps[top_tie, 6, :], fx["state"][top_tie, 0:3])
+    # fp16 coefficients (config 5's storage): the same bodies, coefficients rounded to half first
+    p16 = fx["params"].copy(); p16[:, 3:10] = p16[:, 3:10].astype(np.float16).astype(np.float32)
+    f16, t16 = run_ext(fx["state"], fx["prev"], fx["params"], rho, g, dt, coeff="f16")
+    rf, rt, _ = ho.step_wrench(fx["state"], fx["prev"], p16, rho, g, dt)
+    assert ho.wrench_error(f16, t16, rf, rt, p16, rho, g).max() <= GATE
 
 
 def test_engine_lifetime_does_not_leak(native_built):
