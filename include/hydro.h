@@ -70,8 +70,10 @@ int         hydro_device_count(int *count);
  * Device memory: 68 B per body of capacity - the tiled parameter record (44 B) and the tiled previous velocity
  * (24 B) - plus 1/16 B of reduction scratch.  The entry points that take PLAIN field pointers (hydro_step_wrench,
  * hydro_step_wrench_ext, hydro_step_components) work on plain-SoA copies of the parameters / previous velocity
- * (82 B per body more) that are made on their FIRST call - which therefore allocates and synchronises once and
- * cannot be captured into a HIP graph; call it once before capturing, or hydro_reserve_soa() up front. */
+ * (82 B per body more, + 14 B for the fp16 coefficient copy) that are made on their FIRST call - which therefore
+ * allocates and synchronises once and cannot be captured into a HIP graph; call it once before capturing, or
+ * hydro_reserve_soa() up front - before or after hydro_set_params_*: once the copies exist, hydro_set_params_* keeps
+ * them current and the step path neither allocates nor synchronises. */
 int         hydro_create(int device, int64_t capacity, hydro_t **out);
 int         hydro_reserve_soa(hydro_t *h);
 int         hydro_destroy(hydro_t *h);
@@ -104,7 +106,9 @@ int hydro_set_semantics(hydro_t *h, int semantics);
  * (numba_hydrodynamics_wrapper.py:9-32) plus the rigid-body mass used by the clamp
  * (hydrodynamics_behavior.py:172-173,222).  `params[f]` points at n floats; `on_device` says
  * where those arrays live.  _f16 stores the seven coefficients as IEEE half in HBM (config 5:
- * 130 B per body-step instead of 144); dims and mass stay fp32; the arithmetic is fp64 either way. */
+ * 130 B per body-step instead of 144); dims and mass stay fp32; the arithmetic is fp64 either way.
+ * Synchronous on the engine's private stream; the caller orders it after steps of this engine still in flight on
+ * OTHER streams (they read the records this call rewrites). */
 int hydro_set_params_f32(hydro_t *h, int64_t n, const float *const params[HYDRO_PARAM_FIELDS], int on_device);
 int hydro_set_params_f16(hydro_t *h, int64_t n, const float *const params[HYDRO_PARAM_FIELDS], int on_device);
 
@@ -153,9 +157,9 @@ int hydro_step_wrench_tiled(hydro_t *h, int64_t n, const float *state, int64_t s
 
 /* The same step, sampling the kinetic energy on the way ("reduced in-kernel"): the kernel adds
  * 1/2 m |v|^2 (and, with `rotational`, the box-inertia term) of the bodies it already holds in registers - the state
- * it READS, i.e. the state the previous step left - reduces over the wavefront and the block, and a fixed-order
- * second stage leaves [translational, rotational] in ke_out_dev[0..1] (device memory, fp64).  No second pass over
- * the state, the wrench bits are those of hydro_step_wrench_tiled, the energy bits those of
+ * it READS, i.e. the state the previous step left - reduces over the block (LDS) and the wavefront, and the block
+ * that finishes last adds the per-block pairs in a fixed order into ke_out_dev[0..1] (device memory, fp64; same launch).
+ * No second pass over the state, no second launch, the wrench bits are those of hydro_step_wrench_tiled, the energy bits those of
  * hydro_kinetic_energy_tiled on the same state.  For the monitor that all-reduces the pair over RCCL every K steps. */
 int hydro_step_wrench_tiled_ke(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride,
                                const float *prev, int64_t prev_tile_stride, double dt,
@@ -202,12 +206,14 @@ int hydro_step_components_aos(hydro_t *h, int64_t n, const float *position, cons
                               const float *angular_accel, float *const out[8], float *ratio, void *stream);
 
 /* Kinetic energy of the n bodies: out_dev[0] = sum 1/2 m |v|^2, out_dev[1] = sum 1/2 w^T I w (box
- * inertia; 0 unless `rotational`), every body in fp64.  Two-stage deterministic reduction on device (wave64
- * shuffles -> LDS -> one fp64 pair per block of 256 bodies -> fixed-order second stage, no atomics); the
- * result stays on the device so that the caller can all-reduce it over RCCL.  New
- * functionality named by BASELINE.json north_star; absent from the reference.
+ * inertia; 0 unless `rotational`), every body in fp64.  Deterministic reduction on device in ONE launch: the four
+ * bodies a lane owns in a group of 256 -> wave64 shuffle tree -> one fp64 pair per group -> the block that draws the
+ * last ticket (one integer atomic per block; no floating-point atomics) adds the pairs in a fixed order.  The result
+ * does not depend on the order in which blocks run; it stays on the device so that the caller can all-reduce it over
+ * RCCL.  New functionality named by BASELINE.json north_star; absent from the reference.
  * These are the stand-alone entries (one pass over the state: 56 B per body with the rotational term);
- * hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke sample the same pair, same bits, inside a step. */
+ * hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke sample the same pair, same bits, inside a step.
+ * All of them use the engine's reduction scratch: do not overlap two of them on one engine (two streams). */
 int hydro_kinetic_energy(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], int rotational,
                          double *out_dev, void *stream);
 int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride, int rotational,

@@ -149,7 +149,7 @@ class _Group:
         self.members: list["HydrodynamicsBehavior"] = []
         self.member_set: set = set()
         self.callback_members = 0           # members in "callbacks" mode (their per-prim counters need levelling)
-        self._rows: dict = {}               # id(member) -> row of the current batch
+        self._rows: dict = {}               # member -> row of the current batch (the object, not its id: ids are reused)
         self.view: BodyView | None = None
         self.engine: HydroEngine | None = None
         self.dirty = True
@@ -174,6 +174,7 @@ class _Group:
 
     def discard(self, b: "HydrodynamicsBehavior") -> None:
         self.member_set.discard(b)
+        self._rows.pop(b, None)             # its previous velocity leaves with it
         self.dirty = True
         if not b._scene_mode:
             self.callback_members -= 1
@@ -214,7 +215,7 @@ class _Group:
         carried = None
         if self.engine is not None:
             if self.steps > 0 and self._rows:
-                carried = (self.engine.get_prev_velocity(), self._rows)
+                carried = (self.engine.get_prev_velocity(), dict(self._rows))
             self.engine.close()
         if len(self.members) != len(self.member_set):
             self.members = [m for m in self.members if m in self.member_set]
@@ -232,10 +233,10 @@ class _Group:
         self.force = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
         self.torque = torch.empty((n, 3), dtype=torch.float32, device=self.engine.device)
         self._stepper = _AosStepper(self.engine, self.force, self.torque)
-        self._rows = {id(m): i for i, m in enumerate(self.members)}
+        self._rows = {m: i for i, m in enumerate(self.members)}
         if carried is not None:
             old_prev, old_rows = carried
-            pairs = [(old_rows[id(m)], i) for i, m in enumerate(self.members) if id(m) in old_rows]
+            pairs = [(old_rows[m], i) for i, m in enumerate(self.members) if m in old_rows]
             if pairs:
                 src = torch.tensor([p[0] for p in pairs], dtype=torch.long, device=old_prev.device)
                 dst = torch.tensor([p[1] for p in pairs], dtype=torch.long, device=old_prev.device)
@@ -284,7 +285,10 @@ class EngineRegistry:
         self._groups: dict[tuple, _Group] = {}
 
     def register(self, b: "HydrodynamicsBehavior") -> _Group:
-        key = (id(b._host), float(b._rho), float(b._g), b.SEMANTICS)
+        # the subscription mode is part of the key: a group is driven EITHER by its own subscription (scene mode) or by
+        # its members' callbacks - mixed, a step could run the batch twice (once from a member's callback, once from the
+        # group's subscription), the second time against an already-updated previous velocity
+        key = (id(b._host), float(b._rho), float(b._g), b.SEMANTICS, bool(b._scene_mode))
         grp = self._groups.get(key)
         if grp is None:
             grp = self._groups[key] = _Group(b._host, b._rho, b._g, b.SEMANTICS)

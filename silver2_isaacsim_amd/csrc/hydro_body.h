@@ -452,7 +452,7 @@ HYDRO_FN void kinetic_energy(float fqx, float fqy, float fqz, float fqw, float f
         const double wx = fwx, wy = fwy, wz = fwz;
         const double bx = r00 * wx + r10 * wy + r20 * wz, by = r01 * wx + r11 * wy + r21 * wz, bz = r02 * wx + r12 * wy + r22 * wz;
         const double dx = fdx, dy = fdy, dz = fdz;
-        const double k = m / 12.0;
+        const double k = m * (1.0 / 12.0);
         rot = 0.5 * k * ((dy * dy + dz * dz) * (bx * bx) + (dx * dx + dz * dz) * (by * by) + (dx * dx + dy * dy) * (bz * bz));
     }
 }

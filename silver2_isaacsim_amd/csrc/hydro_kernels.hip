@@ -62,7 +62,6 @@
 namespace {
 
 constexpr int kBlock = 256;                // 4 waves of 64 lanes
-constexpr int kKeFinalBlock = 1024;        // threads of the second stage of the kinetic-energy reduction
 // Occupancy: the fp64 body needs 98-132 VGPRs depending on the kernel around it and on the build flags, i.e. 3-4 waves
 // per SIMD.  Forcing a number (__launch_bounds__' second argument) made the compiler spill 2-4 registers on the path
 // every wave runs when the kernel needed 130: measured 28.2 vs 24.0 us at 1 M bodies - the
@@ -238,8 +237,20 @@ __device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t
 
 
 // --------------------------------------------------------------------------
-// block-level reduction of the kinetic-energy pair (used by the stand-alone first stage and by the wrench / step
-// kernels that sample the energy of the bodies they hold: see "kinetic energy" below)
+// kinetic-energy reduction ("wave64 shuffle -> LDS -> one fp64 partial per block -> deterministic second
+// stage"), all of it inside ONE launch.
+//
+// The decomposition is the same whether the first stage runs stand-alone (ke_kernel) or inside a wrench / step kernel
+// that has the bodies in registers anyway (their KE template argument) - both give the same bits:
+//   1. bodies are grouped by 256 consecutive indices (4 tiles); lane l of a group adds ITS four bodies - indices
+//      256 g + l, + 64, + 128, + 192 - in that order:   x_l = ((b0 + b1) + b2) + b3   (absent bodies count +0.0);
+//   2. the 64 lane sums go through the wave64 shuffle tree (offsets 32, 16, ... 1) -> partial P_g, stored at partials[g];
+//   3. every block takes a ticket (device-scope atomic); the block that draws the LAST one adds the partials in a fixed
+//      order - thread t of 256 takes t, t + 256, ... in index order, then the shuffle tree per wave, then the four wave
+//      sums in order - and writes the pair.  No second launch (a dependent 1-block launch cost 2-4 us, as much as the
+//      first stage of 500 k bodies), no floating-point atomics, a result that does not depend on which block came last.
+// The ticket counter lives behind the partials ([2][stride] doubles, then one 64-bit slot) and is reset by the block that
+// finishes, so a launch leaves it at 0: launches on one engine must not overlap (a handle is not thread-safe anyway).
 // --------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double x)
 {
@@ -248,19 +259,68 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-// every thread of a 256-thread block calls this (idle lanes with zeros); partials = [2][stride]
-__device__ __forceinline__ void ke_block_partial(double lin, double rot, double* __restrict__ partials, uint32_t stride)
+// Step 2 for ONE wavefront holding the 64 lane sums of group `group`: tree, lane 0 stores the partial write-through at
+// device scope (the block that finishes may run on another XCD, behind another L2).
+__device__ __forceinline__ void ke_store_partial(double lin, double rot, uint32_t group, double* __restrict__ partials, uint32_t stride)
 {
-    __shared__ double red[2][kBlock / 64];
     lin = wave_sum(lin);
     rot = wave_sum(rot);
+    if ((threadIdx.x & 63u) == 0) {
+        __hip_atomic_store(partials + group, lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partials + stride + group, rot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Step 3.  Every thread of a 256-thread block calls this after the block's partials have been stored (by ke_store_partial,
+// in any of its waves).  `groups` = number of partials of the launch; the launch has gridDim.x blocks.
+__device__ __forceinline__ void ke_finish_block(double* __restrict__ partials, uint32_t stride, uint32_t groups, double* __restrict__ out)
+{
+    __shared__ uint32_t last_block;
+    __shared__ double red[2][kBlock / 64];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this wave's partial is on its way to memory ...
+    __syncthreads();                                            // ... and so are the other waves'
+    if (threadIdx.x == 0) {
+        uint32_t* counter = reinterpret_cast<uint32_t*>(partials + 2 * (size_t)stride);
+        const uint32_t ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = (ticket == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_block) return;                                     // (uniform over the block)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double l = 0.0, r = 0.0;
+#pragma unroll 8
+    for (uint32_t k = threadIdx.x; k < groups; k += kBlock) {
+        l += __hip_atomic_load(partials + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r += __hip_atomic_load(partials + stride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    l = wave_sum(l);
+    r = wave_sum(r);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = lin; red[1][wave] = rot; }
+    if (lane == 0) { red[0][wave] = l; red[1][wave] = r; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        partials[stride + blockIdx.x] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        out[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        out[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(partials + 2 * (size_t)stride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// The form the wrench / step kernels use: one block = one group, wave w holds tile w in its lanes.  Step 1 goes through
+// LDS (the four waves' lane values side by side), wave 0 does step 2, everybody step 3.  Every thread of the block calls
+// this (lanes without a body with zeros).
+__device__ __forceinline__ void ke_block_reduce(double lin, double rot, double* __restrict__ partials, uint32_t stride, double* __restrict__ out)
+{
+    __shared__ double stage[2][kBlock];
+    stage[0][threadIdx.x] = lin;
+    stage[1][threadIdx.x] = rot;
+    __syncthreads();
+    if (threadIdx.x < 64u) {
+        const uint32_t l = threadIdx.x;
+        const double a = ((stage[0][l] + stage[0][64 + l]) + stage[0][128 + l]) + stage[0][192 + l];
+        const double b = ((stage[1][l] + stage[1][64 + l]) + stage[1][128 + l]) + stage[1][192 + l];
+        ke_store_partial(a, b, blockIdx.x, partials, stride);
+    }
+    ke_finish_block(partials, stride, gridDim.x, out);
 }
 
 // --------------------------------------------------------------------------
@@ -436,7 +496,7 @@ template <int BLOCK, bool HALF, bool WRITE_PREV, bool NT, bool KE, bool WARP>
 __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_out, float* k_pv_out,
                                                              uint32_t st_stride, uint32_t pv_stride, uint32_t out_stride, uint32_t pvo_stride,
                                                              uint32_t n, int warp, double rho, double g, double inv_dt,
-                                                             double* ke_partials, uint32_t ke_stride, int ke_rotational)
+                                                             double* ke_partials, uint32_t ke_stride, int ke_rotational, double* ke_out)
 {
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pv_out; a.pvo_stride = pvo_stride;
@@ -493,7 +553,7 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
     }
     if constexpr (KE) {
         static_assert(BLOCK == kBlock, "the kinetic-energy partials are one per 256 bodies");
-        ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
+        ke_block_reduce(ke_lin, ke_rot, ke_partials, ke_stride, ke_out);
     }
 }
 
@@ -829,66 +889,66 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
 }
 
 // --------------------------------------------------------------------------
-// kinetic energy: per body in fp64 (hydro_body.h), wave64 shuffle -> LDS across the block's 4 waves -> ONE fp64
-// pair per block of 256 consecutive bodies -> fixed-order second stage.  Deterministic, no atomics; the
-// decomposition (which bodies make which partial, in which order everything is added) is the same whether the
-// first stage runs stand-alone (ke_partial_kernel) or inside a wrench / step kernel that has the bodies in
-// registers anyway (KE template argument there): both give the same bits.
+// kinetic energy, stand-alone (hydro_kinetic_energy[_tiled]): one pass over 56 B per body with the rotational term (40
+// of the 52 state bytes + dimensions and mass), 20 B without - a pure streaming kernel, HBM-bound.
+// A WAVEFRONT takes one group of 256 consecutive bodies = four tiles: all its 44 (16) loads are issued before the first
+// use, so a wave has 11 KB in flight and its one shuffle tree is paid per 256 bodies, not per 64; the four waves of a
+// block share nothing until the ticket (ke_finish_block).  State from plain SoA field pointers or from a tiled buffer
+// (one address rule, see IntArgs); dimensions and mass from the engine's tiled parameter record.
 // --------------------------------------------------------------------------
-// Stand-alone first stage: one body per lane, every load issued before the first use.  State from plain SoA field
-// pointers or from a tiled buffer (one address rule, see IntArgs); dimensions and mass from the engine's tiled
-// parameter record.  56 B read per body with the rotational term (40 of the 52 state bytes + 16), 16 + 4 without.
 struct KeArgs {
     const float* st[HYDRO_STATE_FIELDS];   // plain SoA field pointers, or tiled base + f*64
     uint32_t st_stride, shift, mask;
     const float* prm;                      // engine-owned tiled parameter record
     uint32_t prm_tile_floats, mass_field;  // 704 / 10 (fp32 record) or 480 / 3 (fp16-coefficient record)
     double* partials; uint32_t partial_stride;
-    int rotational;
+    double* out;
     uint32_t n;
 };
 
-__global__ void __launch_bounds__(kBlock) ke_partial_kernel(const KeArgs a)
+template <bool ROT>
+__global__ void __launch_bounds__(kBlock) ke_kernel(const KeArgs a)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    double lin = 0.0, rot = 0.0;
-    if (i < a.n) {
-        const uint32_t o = (i >> a.shift) * a.st_stride + (i & a.mask);
-        const float* q = a.prm + (size_t)(i >> 6) * a.prm_tile_floats + (i & 63u);
-        const float m = __builtin_nontemporal_load(q + a.mass_field * 64u);
-        const float vx = __builtin_nontemporal_load(a.st[7] + o), vy = __builtin_nontemporal_load(a.st[8] + o), vz = __builtin_nontemporal_load(a.st[9] + o);
-        float qx = 0.f, qy = 0.f, qz = 0.f, qw = 1.f, wx = 0.f, wy = 0.f, wz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-        if (a.rotational) {
-            qx = __builtin_nontemporal_load(a.st[3] + o); qy = __builtin_nontemporal_load(a.st[4] + o);
-            qz = __builtin_nontemporal_load(a.st[5] + o); qw = __builtin_nontemporal_load(a.st[6] + o);
-            wx = __builtin_nontemporal_load(a.st[10] + o); wy = __builtin_nontemporal_load(a.st[11] + o); wz = __builtin_nontemporal_load(a.st[12] + o);
-            dx = __builtin_nontemporal_load(q); dy = __builtin_nontemporal_load(q + 64); dz = __builtin_nontemporal_load(q + 128);
-        }
-        hydro::kinetic_energy(qx, qy, qz, qw, vx, vy, vz, wx, wy, wz, dx, dy, dz, m, a.rotational != 0, lin, rot);
-    }
-    ke_block_partial(lin, rot, a.partials, a.partial_stride);
-}
-
-// Second stage: ONE block adds the per-block partials in a fixed order: thread t takes t, t + 1024, ... (batches of
-// eight loads in flight), then the wave64 shuffle tree, then the 16 wave sums in order.  One workgroup barrier.
-__global__ void __launch_bounds__(kKeFinalBlock) ke_final_kernel(const double* __restrict__ partials, uint32_t nblocks, uint32_t stride,
-                                                                 double* __restrict__ out)
-{
-    __shared__ double red[2][kKeFinalBlock / 64];
-    double l = 0.0, r = 0.0;
-#pragma unroll 8
-    for (uint32_t k = threadIdx.x; k < nblocks; k += kKeFinalBlock) { l += partials[k]; r += partials[stride + k]; }
-    l = wave_sum(l);
-    r = wave_sum(r);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = l; red[1][wave] = r; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sl = 0.0, sr = 0.0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t groups = (a.n + 255u) >> 8;
+    const uint32_t group = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (group < groups) {                                        // (uniform over the wave; no return: the block meets again below)
+        float m[4], v[3][4], q[4][4], w[3][4], d[3][4];
 #pragma unroll
-        for (int w = 0; w < kKeFinalBlock / 64; ++w) { sl += red[0][w]; sr += red[1][w]; }
-        out[0] = sl; out[1] = sr;
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t i = (group << 8) + t * 64u + lane;
+            m[t] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v[k][t] = 0.f; w[k][t] = 0.f; d[k][t] = 0.f; }
+            q[0][t] = q[1][t] = q[2][t] = 0.f; q[3][t] = 1.f;
+            if (i < a.n) {                                       // (a body that is not there adds +0.0)
+                // state: field base pointers in SGPRs + one 32-bit byte offset (i < 2^30; tiled buffers < 4 GiB);
+                // parameter record: one 64-bit address per tile, field offsets in the instruction
+                const uint32_t o = ((i >> a.shift) * a.st_stride + (i & a.mask)) * 4u;
+                const float* pr = a.prm + (size_t)(i >> 6) * a.prm_tile_floats + lane;
+                m[t] = __builtin_nontemporal_load(pr + a.mass_field * 64u);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k][t] = ldg<true>(at<float>(a.st[7 + k], o));
+                if constexpr (ROT) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k][t] = ldg<true>(at<float>(a.st[3 + k], o));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { w[k][t] = ldg<true>(at<float>(a.st[10 + k], o)); d[k][t] = __builtin_nontemporal_load(pr + k * 64); }
+                }
+            }
+        }
+        double lin = 0.0, rot = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double l, r;
+            hydro::kinetic_energy(q[0][t], q[1][t], q[2][t], q[3][t], v[0][t], v[1][t], v[2][t], w[0][t], w[1][t], w[2][t],
+                                  d[0][t], d[1][t], d[2][t], m[t], ROT, l, r);
+            lin = t ? lin + l : l;
+            rot = t ? rot + r : r;
+        }
+        ke_store_partial(lin, rot, group, a.partials, a.partial_stride);
     }
+    ke_finish_block(a.partials, a.partial_stride, groups, a.out);
 }
 
 // --------------------------------------------------------------------------
@@ -1021,7 +1081,7 @@ template <bool HALF, bool NT, bool IMPLICIT, bool KE, bool WARP>
 __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_so, float* k_out,
                                                                  uint32_t st_stride, uint32_t pv_stride, uint32_t so_stride, uint32_t out_stride,
                                                                  uint32_t n, int warp, float dt, double rho, double g, double inv_dt,
-                                                                 double* ke_partials, uint32_t ke_stride, int ke_rotational)
+                                                                 double* ke_partials, uint32_t ke_stride, int ke_rotational, double* ke_out)
 {
     FusedArgs fa;                               // (scalar arguments: see wrench_tiled_kernel)
     fa.t.st = k_st; fa.t.st_stride = st_stride; fa.t.pv = k_pv; fa.t.pv_stride = pv_stride; fa.t.pv_out = nullptr; fa.t.pvo_stride = 0;
@@ -1056,7 +1116,7 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k
             for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(a.out, wo, f * 256u), f6[f]);
         }
     }
-    if constexpr (KE) ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
+    if constexpr (KE) ke_block_reduce(ke_lin, ke_rot, ke_partials, ke_stride, ke_out);
 }
 
 // --------------------------------------------------------------------------
@@ -1072,7 +1132,7 @@ template <bool HALF, bool NT, bool IMPLICIT, bool KE, bool WARP>
 __global__ void __launch_bounds__(kBlock) step_fused_multi_tiled_kernel(const float* k_st, const float* k_pv, const float* k_prm, float* k_so, float* k_pvo,
                                                                        uint32_t st_stride, uint32_t pv_stride, uint32_t so_stride, uint32_t pvo_stride,
                                                                        uint32_t n, uint32_t steps, float dt, double rho, double g, double inv_dt,
-                                                                       double* ke_partials, uint32_t ke_stride, int ke_rotational)
+                                                                       double* ke_partials, uint32_t ke_stride, int ke_rotational, double* ke_out)
 {
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pvo; a.pvo_stride = pvo_stride;
@@ -1109,7 +1169,7 @@ __global__ void __launch_bounds__(kBlock) step_fused_multi_tiled_kernel(const fl
 #pragma unroll
         for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(k_so, oo, f * 256u), s[f]);
     }
-    if constexpr (KE) ke_block_partial(ke_lin, ke_rot, ke_partials, ke_stride);
+    if constexpr (KE) ke_block_reduce(ke_lin, ke_rot, ke_partials, ke_stride, ke_out);
 }
 
 }  // namespace
@@ -1199,24 +1259,31 @@ void fill_params(hydro_engine* h, Args& a)
 inline uint32_t prm_tile_floats(const hydro_engine* h) { return h->half_coeffs ? kPrmTileF16 : kPrmTileF32; }
 inline uint32_t prm_mass_field(const hydro_engine* h) { return h->half_coeffs ? 3u : 10u; }
 
-// The plain-SoA copies of the parameters, made from the tiled record on the first use of a plain-SoA entry point
-// (and after every hydro_set_params_* from then on).  Allocates: not capturable on that first use - call the entry
-// once, or hydro_reserve_soa, before capturing a graph.
-int ensure_soa_params(hydro_engine* h, hipStream_t s)
+// The plain-SoA copies of the parameters (for the entry points that take plain field pointers).  They are ALLOCATED on
+// the first use of such an entry, or by hydro_reserve_soa; once they exist every hydro_set_params_* refreshes them in
+// place (it synchronises anyway), so the step path itself never allocates or synchronises again - which is what makes
+// a plain-SoA step capturable after hydro_reserve_soa, in any order with hydro_set_params_*.
+int refresh_soa_params(hydro_engine* h)
+{
+    if (h->n_params > 0) {
+        hipLaunchKernelGGL(params_from_tiled_kernel, dim3(grid_for(h->n_params, kBlock)), dim3(kBlock), 0, h->stream,
+                           h->params_tiled, h->half_coeffs ? 1 : 0, h->params, h->stride, h->coeffs16, (uint32_t)h->n_params);
+        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+        HYDRO_HIP(h, hipStreamSynchronize(h->stream), HYDRO_E_LAUNCH);      // later calls may come on other streams
+    }
+    h->soa_params_valid = true;
+    return HYDRO_OK;
+}
+
+int ensure_soa_params(hydro_engine* h)
 {
     const size_t fbytes = sizeof(float) * (size_t)h->stride;
     if (!h->params && hipMalloc(&h->params, fbytes * HYDRO_PARAM_FIELDS) != hipSuccess)
         return fail(h, HYDRO_E_ALLOC, "plain-SoA parameter copy: allocation failed (first use of a plain-SoA entry point allocates; not inside a graph capture)");
-    if (h->half_coeffs && !h->coeffs16 && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) != hipSuccess)
+    // (the fp16 copy is allocated with the fp32 one, whatever the current mode: hydro_set_params_f16 may come later)
+    if (!h->coeffs16 && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) != hipSuccess)
         return fail(h, HYDRO_E_ALLOC, "plain-SoA fp16 coefficient copy: allocation failed");
-    if (!h->soa_params_valid && h->n_params > 0) {
-        hipLaunchKernelGGL(params_from_tiled_kernel, dim3(grid_for(h->n_params, kBlock)), dim3(kBlock), 0, s,
-                           h->params_tiled, h->half_coeffs ? 1 : 0, h->params, h->stride, h->coeffs16, (uint32_t)h->n_params);
-        HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-        HYDRO_HIP(h, hipStreamSynchronize(s), HYDRO_E_LAUNCH);      // once: later calls may come on other streams
-    }
-    h->soa_params_valid = true;
-    return HYDRO_OK;
+    return h->soa_params_valid ? HYDRO_OK : refresh_soa_params(h);
 }
 
 int ensure_soa_prev(hydro_engine* h)
@@ -1334,7 +1401,7 @@ int step_soa(hydro_engine* h, int64_t n, const float* const state[], const float
     }
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = ensure_soa_params(h, s))) return rc;                 // plain-SoA parameter copies: made on first use
+    if ((rc = ensure_soa_params(h))) return rc;                    // plain-SoA parameter copies: made on first use
     fill_params(h, a);
     a.mass = h->params + 10 * h->stride;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics;
@@ -1387,7 +1454,8 @@ int set_params(hydro_engine* h, int64_t n, const float* const params[], int on_d
     }
     h->half_coeffs = half;
     h->n_params = n;
-    h->soa_params_valid = false;                 // the plain-SoA copies (if any entry point ever asked for them) are refreshed on next use
+    h->soa_params_valid = false;
+    if (h->params) return refresh_soa_params(h); // the plain-SoA copies exist (an entry point asked for them, or hydro_reserve_soa): keep them current
     return HYDRO_OK;
 }
 
@@ -1414,12 +1482,10 @@ int check_tiled(hydro_engine* h, int64_t n, const void* p, int64_t stride, int f
     return HYDRO_OK;
 }
 
-// second stage of the kinetic-energy reduction for the first `n` bodies' per-block partials
-int ke_finish(hydro_engine* h, int64_t n, double* out_dev, hipStream_t s)
+// the kinetic energy of no bodies (the kernels that sample it are not launched for n == 0)
+int ke_of_nothing(hydro_engine* h, double* out_dev, hipStream_t s)
 {
-    const uint32_t blocks = (uint32_t)grid_for(n > 0 ? n : 1, kBlock);
-    hipLaunchKernelGGL(ke_final_kernel, dim3(1), dim3(kKeFinalBlock), 0, s, h->ke_partials, n > 0 ? blocks : 0u, h->ke_stride, out_dev);
-    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    HYDRO_HIP(h, hipMemsetAsync(out_dev, 0, 2 * sizeof(double), s), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
 
@@ -1492,7 +1558,9 @@ int hydro_create(int device, int64_t capacity, hydro_t** out)
     ok = ok && hipMalloc(&h->params_tiled, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
     ok = ok && hipMalloc(&h->prev_tiled, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
     ok = ok && hipMemsetAsync(h->prev_tiled, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
-    ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * 2 * (size_t)h->ke_stride) == hipSuccess;
+    // [2][ke_stride] partials + the ticket counter of the reduction (zero between launches, see ke_finish_block)
+    ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * (2 * (size_t)h->ke_stride + 1)) == hipSuccess;
+    ok = ok && hipMemsetAsync(h->ke_partials, 0, sizeof(double) * (2 * (size_t)h->ke_stride + 1), h->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
     if (!ok) { hydro_destroy(h); return HYDRO_E_ALLOC; }
     *out = h;
@@ -1518,7 +1586,7 @@ int hydro_reserve_soa(hydro_t* h)
 {
     if (!h) return HYDRO_E_ARG;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    int rc = ensure_soa_params(h, h->stream);
+    int rc = ensure_soa_params(h);
     if (rc) return rc;
     if ((rc = ensure_soa_prev(h))) return rc;
     if (h->prev_current == hydro_engine::kPrevTiled && h->n_params > 0) {      // bring the plain copy up to date
@@ -1665,7 +1733,7 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
     const bool own_prev = (prev == nullptr);
     if (!own_prev && (rc = check_tiled(h, n, prev, prev_tile_stride, HYDRO_PREV_FIELDS, "null prev"))) return rc;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
-    if (n == 0) return ke_out ? ke_finish(h, 0, ke_out, static_cast<hipStream_t>(stream)) : HYDRO_OK;
+    if (n == 0) return ke_out ? ke_of_nothing(h, ke_out, static_cast<hipStream_t>(stream)) : HYDRO_OK;
     TiledArgs a;
     a.st = state; a.st_stride = (uint32_t)state_tile_stride;
     if (own_prev) { a.pv = h->prev_tiled; a.pv_stride = HYDRO_PREV_FIELDS * HYDRO_TILE; a.pv_out = h->prev_tiled; a.pvo_stride = a.pv_stride; }
@@ -1688,7 +1756,7 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
         if (lds > 64 * 1024) lds = 64 * 1024;                               // per-block LDS limit
     }
 #define HYDRO_TILED_ARGS a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt, \
-        h->ke_partials, h->ke_stride, ke_rotational
+        h->ke_partials, h->ke_stride, ke_rotational, ke_out
 #define HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, NT) do { if (a.warp) hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT, false, true>), grid, blk, lds, s, HYDRO_TILED_ARGS); \
         else hipLaunchKernelGGL((wrench_tiled_kernel<BLOCK, HALF, WP, NT, false, false>), grid, blk, lds, s, HYDRO_TILED_ARGS); } while (0)
 #define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
@@ -1741,7 +1809,7 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
 #undef HYDRO_TILED_LAUNCH
 #undef HYDRO_TILED_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    return ke_out ? ke_finish(h, n, ke_out, s) : HYDRO_OK;
+    return HYDRO_OK;
 }
 }  // namespace
 
@@ -1805,7 +1873,7 @@ int step_fused_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t sta
     if (state_out == state) return fail(h, HYDRO_E_ARG, "state_out must not alias state (it may alias the previous-state buffer)");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n == 0) return ke_out ? ke_finish(h, 0, ke_out, s) : HYDRO_OK;
+    if (n == 0) return ke_out ? ke_of_nothing(h, ke_out, s) : HYDRO_OK;
     FusedArgs fa;
     TiledArgs& a = fa.t;
     a.st = state; a.st_stride = (uint32_t)state_tile_stride;
@@ -1817,7 +1885,7 @@ int step_fused_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t sta
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
 #define HYDRO_FUSED_ARGS a.st, a.pv, a.prm, fa.so, a.out, a.st_stride, a.pv_stride, fa.so_stride, a.out_stride, a.n, a.warp, fa.dt, a.rho, a.g, a.inv_dt, \
-        h->ke_partials, h->ke_stride, ke_rotational
+        h->ke_partials, h->ke_stride, ke_rotational, ke_out
 #define HYDRO_FUSED_W(HALF, NT, KE, WARP) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, true, KE, WARP>), grid, blk, 0, s, HYDRO_FUSED_ARGS); \
                                                else hipLaunchKernelGGL((step_fused_tiled_kernel<HALF, NT, false, KE, WARP>), grid, blk, 0, s, HYDRO_FUSED_ARGS); } while (0)
 #define HYDRO_FUSED_I(HALF, NT, KE) do { if (a.warp) HYDRO_FUSED_W(HALF, NT, KE, true); else HYDRO_FUSED_W(HALF, NT, KE, false); } while (0)
@@ -1829,7 +1897,7 @@ int step_fused_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t sta
 #undef HYDRO_FUSED_W
 #undef HYDRO_FUSED_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    return ke_out ? ke_finish(h, n, ke_out, s) : HYDRO_OK;
+    return HYDRO_OK;
 }
 }  // namespace
 
@@ -1872,14 +1940,14 @@ int hydro_step_fused_tiled_multi(hydro_t* h, int64_t n, const float* state, int6
     if (state_out == state) return fail(h, HYDRO_E_ARG, "state_out must not alias state (it may alias the previous-state buffer)");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n == 0) return ke_out_dev ? ke_finish(h, 0, ke_out_dev, s) : HYDRO_OK;
+    if (n == 0) return ke_out_dev ? ke_of_nothing(h, ke_out_dev, s) : HYDRO_OK;
     const double inv_dt = 1.0 / dt;
     const float dtf = (float)dt;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
     const int ke_rot = rotational ? 1 : 0;
 #define HYDRO_MULTI_ARGS state, prev, h->params_tiled, state_out, prev_out, (uint32_t)state_tile_stride, (uint32_t)prev_tile_stride, (uint32_t)out_tile_stride, \
-        (uint32_t)prev_out_tile_stride, (uint32_t)n, (uint32_t)steps, dtf, h->rho, h->g, inv_dt, h->ke_partials, h->ke_stride, ke_rot
+        (uint32_t)prev_out_tile_stride, (uint32_t)n, (uint32_t)steps, dtf, h->rho, h->g, inv_dt, h->ke_partials, h->ke_stride, ke_rot, ke_out_dev
 #define HYDRO_MULTI_W(HALF, NT, KE, WARP) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_multi_tiled_kernel<HALF, NT, true, KE, WARP>), grid, blk, 0, s, HYDRO_MULTI_ARGS); \
                                                else hipLaunchKernelGGL((step_fused_multi_tiled_kernel<HALF, NT, false, KE, WARP>), grid, blk, 0, s, HYDRO_MULTI_ARGS); } while (0)
 #define HYDRO_MULTI_I(HALF, NT, KE) do { if (h->semantics) HYDRO_MULTI_W(HALF, NT, KE, true); else HYDRO_MULTI_W(HALF, NT, KE, false); } while (0)
@@ -1891,7 +1959,7 @@ int hydro_step_fused_tiled_multi(hydro_t* h, int64_t n, const float* state, int6
 #undef HYDRO_MULTI_W
 #undef HYDRO_MULTI_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
-    return ke_out_dev ? ke_finish(h, n, ke_out_dev, s) : HYDRO_OK;
+    return HYDRO_OK;
 }
 
 int hydro_pack_state_aos(hydro_t* h, int64_t n, const float* positions, const float* orientations, int quat_xyzw,
@@ -2002,7 +2070,7 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
     for (int f = 0; f < HYDRO_COMP_FIELDS; ++f) { if (!comps[f]) return fail(h, HYDRO_E_ARG, "null component field"); a.out[f] = comps[f]; }
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = ensure_soa_params(h, s))) return rc;
+    if ((rc = ensure_soa_params(h))) return rc;
     fill_params(h, a);
     a.ratio = ratio; a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.n = n;
     const int grid = grid_for(n, kBlock);
@@ -2015,11 +2083,15 @@ int hydro_step_components(hydro_t* h, int64_t n, const float* const state[HYDRO_
 static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, double* out_dev, void* stream)
 {
     a.prm = h->params_tiled; a.prm_tile_floats = prm_tile_floats(h); a.mass_field = prm_mass_field(h);
-    a.partials = h->ke_partials; a.partial_stride = h->ke_stride; a.rotational = rotational; a.n = (uint32_t)n;
+    a.partials = h->ke_partials; a.partial_stride = h->ke_stride; a.out = out_dev; a.n = (uint32_t)n;
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n > 0) hipLaunchKernelGGL(ke_partial_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, a);
-    return ke_finish(h, n, out_dev, s);
+    if (n == 0) return ke_of_nothing(h, out_dev, s);
+    const dim3 grid(grid_for(n, kBlock * 4)), blk(kBlock);       // a wavefront per 256 bodies, four of them per block
+    if (rotational) hipLaunchKernelGGL(ke_kernel<true>, grid, blk, 0, s, a);
+    else hipLaunchKernelGGL(ke_kernel<false>, grid, blk, 0, s, a);
+    HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
+    return HYDRO_OK;
 }
 
 int hydro_step_components_aos(hydro_t* h, int64_t n, const float* position, const float* orientation_xyzw,

@@ -132,7 +132,10 @@ class HydroEngine:
         self._check(self._lib.hydro_reset_prev_velocity(self._h))
 
     def get_prev_velocity(self) -> torch.Tensor:
+        """(6, n) copy of the engine-owned previous velocity (checkpoint / resume).  The C call works on the engine's
+        private stream: the step that last wrote the records ran on the caller's, so that one is drained first."""
         out = torch.empty((nat.PREV_FIELDS, self.n), dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
         self._check(self._lib.hydro_get_prev_velocity(self._h, self.n, self._table(out, nat.PREV_FIELDS), 1))
         return out
 

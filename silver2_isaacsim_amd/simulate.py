@@ -168,6 +168,7 @@ class ClosedLoopSim:
         self.steps_done = 0
         self._graph = None
         self._graph_steps = 0
+        self._graph_bufs = None
         # optional global kinetic energy every `ke_every` steps (asynchronous, see KineticEnergyMonitor).  The fused
         # step SAMPLES it for the bodies it has in registers (ke_out=): no extra pass over the state.  With HIP-graph
         # replays the sampling step is the last step of the graph, so `ke_every` must be a multiple of graph_steps.
@@ -211,14 +212,17 @@ class ClosedLoopSim:
             with torch.cuda.graph(g, stream=self.stream):
                 for k in range(graph_steps):
                     self._step_once(sample=self.monitor is not None and k == graph_steps - 1)
-        self._graph, self._graph_steps = g, graph_steps
+        # the graph hard-codes which physical buffer is "current": valid only while the ping-pong is in this phase
+        self._graph, self._graph_steps, self._graph_bufs = g, graph_steps, (self.cur.data_ptr(), self.old.data_ptr())
 
     def run(self, steps: int, graph_steps: int = 64) -> None:
         """Advance `steps` physics steps; full groups of `graph_steps` are graph replays."""
         if graph_steps and steps >= graph_steps:
             if self.steps_done % graph_steps and self.monitor is not None:
                 raise ValueError("with a kinetic-energy monitor, graph replays must start at a multiple of graph_steps")
-            if self._graph is None or self._graph_steps != graph_steps:
+            # (an odd number of eager steps or resident launches since the capture leaves the buffers swapped: a replay
+            # would step the stale one - recapture for the phase the ping-pong is in now)
+            if self._graph is None or self._graph_steps != graph_steps or self._graph_bufs != (self.cur.data_ptr(), self.old.data_ptr()):
                 self._capture(graph_steps)              # capturing records, it does not execute
             with torch.cuda.stream(self.stream):
                 for _ in range(steps // graph_steps):

@@ -25,6 +25,26 @@ def test_graph_replay_equals_eager_stepping(native_built):
     a.close(); b.close()
 
 
+def test_graph_is_recaptured_when_the_ping_pong_phase_changes(native_built):
+    """A captured graph hard-codes which buffer is current.  An odd number of resident launches (or of eager steps)
+    swaps the buffers; a replay of the old graph would then step the stale one: run -> run_resident ->
+    run, and measure_rtf(resident=True) followed by measure_rtf(resident=False), give the bits of eager stepping."""
+    sc = scenes.scene_c2(n=1000)
+    a, b = ClosedLoopSim(sc), ClosedLoopSim(sc)
+    a.run_eager(192)
+    b.run(64); b.run_resident(64); b.run(64)        # one resident launch in between: odd
+    assert np.array_equal(a.state(), b.state()) and b.steps_done == 192
+    b.run_eager(3); b.run(64); a.run_eager(67)       # odd eager remainder, then replays again
+    assert np.array_equal(a.state(), b.state())
+    c, d = ClosedLoopSim(sc), ClosedLoopSim(sc)
+    c.measure_rtf(640, graph_steps=64, resident=True)            # 1 warm + 10 timed launches: odd
+    c.measure_rtf(128, graph_steps=64, resident=False)
+    d.run_eager(64 + 640 + 64 + 128)
+    assert c.steps_done == d.steps_done and np.array_equal(c.state(), d.state())
+    for s_ in (a, b, c, d):
+        s_.close()
+
+
 @pytest.mark.parametrize("name,coeff", [("c2", "f32"), ("c5", "f16")])
 def test_fused_step_equals_wrench_then_integrate(name, coeff, native_built):
     """hydro_step_fused_tiled == hydro_step_wrench_tiled + hydro_integrate_tiled, bit for bit,

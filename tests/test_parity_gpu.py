@@ -357,6 +357,46 @@ def test_kinetic_energy_sampled_inside_the_step_kernels(coeff, n, native_built):
     eng.close()
 
 
+@pytest.mark.parametrize("n", [1048576 + 3, 4194304, 255, 1])
+def test_kinetic_energy_single_launch_reduction_is_order_independent_and_replayable(n, native_built):
+    """The reduction is one launch: the block that draws the last ticket adds the per-group pairs in a fixed order.  Which
+    block that is varies from launch to launch; the bits must not (20 launches), the ticket counter must be back at zero
+    after each (or the next launch would never finish its sum), a captured launch must replay, and the value is the
+    fp64 host sum."""
+    sc = scenes.scene_c4(n=min(n, 65536), seed=9)
+    reps = -(-n // sc.n)
+    state = np.tile(sc.state, (reps, 1))[:n]; params = np.tile(sc.params, (reps, 1))[:n]
+    eng = HydroEngine(n, DEV, sc.rho, sc.g)
+    eng.set_params(params)
+    st = tiled(state)
+    first = eng.kinetic_energy(st, rotational=True).clone()
+    for _ in range(20):
+        assert torch.equal(eng.kinetic_energy(st, rotational=True), first)
+    tot = ho.kinetic_energy(state, params, True)[0]
+    assert first.sum().item() == pytest.approx(tot, rel=1e-12)
+    side = torch.cuda.Stream()
+    out = torch.zeros(2, dtype=torch.float64, device=DEV)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        eng.kinetic_energy(st, rotational=True, out=out)
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            eng.kinetic_energy(st, rotational=True, out=out)
+    for _ in range(5):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+    # the sampling wrench kernel shares the scratch and the ticket: alternate the two
+    prev = tiled(np.tile(sc.prev, (reps, 1))[:n])
+    ke = torch.zeros(2, dtype=torch.float64, device=DEV)
+    for _ in range(3):
+        eng.step_wrench_tiled(st, n, sc.dt, prev=prev, ke_out=ke, rotational=True)
+        assert torch.equal(eng.kinetic_energy(st, rotational=True), first)
+        assert torch.equal(ke, first)
+    eng.close()
+
+
 def test_engine_holds_68_bytes_per_body_until_a_plain_soa_entry_is_used(native_built):
     """The engine's own buffers: tiled parameters (44 B) + tiled previous velocity (24 B) per body of capacity.  The
     plain-SoA copies (82 B more) appear with the first call of an entry point that takes plain field pointers."""
@@ -393,14 +433,22 @@ def test_engine_holds_68_bytes_per_body_until_a_plain_soa_entry_is_used(native_b
     eng.close()
 
 
-def test_plain_soa_step_is_capturable_after_reserve_soa(native_built):
+@pytest.mark.parametrize("order", ["params, reserve", "reserve, params", "reserve, params f16, params f32"])
+def test_plain_soa_step_is_capturable_after_reserve_soa(order, native_built):
     """The first call of a plain-SoA entry allocates the engine's plain copies (not capturable); `reserve_soa` makes
-    them up front, after which the entry is as capture-safe as the others: graph replay == eager call, bit for bit."""
+    them up front, after which the entry is as capture-safe as the others: graph replay == eager call, bit for bit -
+    in whichever order reserve_soa and set_params came (set_params keeps existing copies current: ADVICE r3)."""
     fx = load_golden("c2")
     n, dt = 4096, float(fx["dt"])
     eng = HydroEngine(n, DEV, float(fx["rho"]), float(fx["g"]))
-    eng.set_params(fx["params"][:n])
-    eng.reserve_soa()
+    if order == "params, reserve":
+        eng.set_params(fx["params"][:n])
+        eng.reserve_soa()
+    else:
+        eng.reserve_soa()                                      # nothing to copy yet
+        if "f16" in order:
+            eng.set_params(fx["params"][:n] * np.float32(0.5), "f16")
+        eng.set_params(fx["params"][:n])
     st, pv = soa(fx["state"][:n]), soa(fx["prev"][:n])
     out = torch.zeros((6, n), device=DEV)
     stream = torch.cuda.Stream(DEV)
