@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""DEV-ONLY: interleaved A/B of libhydro.so built with different -D flags (prebuilt here, see BUILD below;
-the variants travel to the GPU box under scripts/_variants/).  Times the C5 headline step (tiled, fp16 coeffs,
-4 rotating replicas) and the fp32 4M step.
-  build (CPU container):  python scripts/ab_variants.py build name1=-DFOO=1 name2=-DFOO=2 ...
+"""DEV-ONLY: interleaved A/B of whole libhydro.so builds (prebuilt here, see `build` below; the variants travel to the
+GPU box under scripts/_variants/).  Times the C5 headline step (tiled, fp16 coeffs, 4 rotating replicas) and the fp32 4M step.
+The product source has ONE code path per kernel: a variant is the product source plus PATCHES from scripts/ab/ (applied to
+a scratch copy, never to the tree) and / or extra compiler flags.
+  build (CPU container):  python scripts/ab_variants.py build base= name1=-mllvm,-foo name2=-DHYDRO_AB_TILED_LDS=1@knobs_r03.patch ...
+                          (flags comma-separated; @patch[+patch...] = files under scripts/ab/.  knobs_r03.patch brings back
+                          the compile-time knobs of rounds 1-3 - HYDRO_AB_* - and the rejected kernels in scripts/ab/*.h)
   run   (GPU box):        python scripts/ab_variants.py run name1 name2 ...        -> gpurun_out/ab.log"""
 import os, statistics, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
@@ -16,14 +19,28 @@ def so(name):
     return os.path.join(VARDIR, f"libvar_{name}.so")
 
 
+def scratch_source(name, patches):
+    """Copy of the product's csrc/ + include/hydro.h (+ the lab headers of scripts/ab/) with `patches` applied."""
+    import glob, shutil, subprocess
+    root = os.path.join(VARDIR, f"src_{name}")
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(os.path.join(root, "pkg", "csrc")); os.makedirs(os.path.join(root, "include"))
+    for f in glob.glob(os.path.join(REPO, "silver2_isaacsim_amd", "csrc", "*")) + glob.glob(os.path.join(REPO, "scripts", "ab", "*.h")):
+        shutil.copy(f, os.path.join(root, "pkg", "csrc"))
+    shutil.copy(os.path.join(REPO, "include", "hydro.h"), os.path.join(root, "include"))
+    for p in patches:
+        subprocess.run(["patch", "-p1", "-i", os.path.join(REPO, "scripts", "ab", p)], cwd=os.path.join(root, "pkg"), check=True)
+    return os.path.join(root, "pkg", "csrc", "hydro_kernels.hip")
+
+
 if sys.argv[1] == "build":
     from silver2_isaacsim_amd import build as hb
-    import shutil
     for spec in sys.argv[2:]:
-        name, _, flags = spec.partition("=")
-        hb.build(force=True, extra_flags=[f for f in flags.split(",") if f])
-        shutil.copy(hb.OUT, so(name)); print("built", so(name), flags)
-    hb.build(force=True)                      # leave the product library as the plain build
+        name, _, rest = spec.partition("=")
+        flags, _, patches = rest.partition("@")
+        src = scratch_source(name, [p for p in patches.split("+") if p])
+        hb.compile_library(src, so(name), [f for f in flags.split(",") if f])
+        print("built", so(name), flags, patches)
     sys.exit(0)
 
 import numpy as np, torch

@@ -7,9 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "hydro_kernels.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "hydro_body.h"),
-        os.path.join(_HERE, "csrc", "hydro_ab_tiled_arms.h"), os.path.join(_HERE, "csrc", "hydro_ab_aos_arm.h"),
-        os.path.join(os.path.dirname(_HERE), "include", "hydro.h")]
+DEPS = [SRC, os.path.join(_HERE, "csrc", "hydro_body.h"), os.path.join(os.path.dirname(_HERE), "include", "hydro.h")]
 OUT = os.path.join(_HERE, "lib", "libhydro.so")
 ARCH = "gfx950"
 
@@ -43,13 +41,11 @@ def device_flags() -> list[str]:
             "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
-    """Compile csrc/hydro_kernels.hip -> lib/libhydro.so.  Returns the library path."""
-    if not force and not is_stale():
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+def compile_library(src: str, out: str, extra_flags: list[str] | None = None, verbose: bool = False) -> str:
+    """hipcc `src` -> shared library `out` with the product's flags (also used by scripts/ab_variants.py for lab builds)."""
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [hipcc_path()] + device_flags() + ["-fPIC", "-shared", "-Wall", "-Wno-unused-function"] \
-        + (extra_flags or []) + ["-o", OUT + ".tmp", SRC]
+        + (extra_flags or []) + ["-o", out + ".tmp", src]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
@@ -57,8 +53,15 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
         print(res.stderr)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed ({res.returncode})")
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    """Compile csrc/hydro_kernels.hip -> lib/libhydro.so.  Returns the library path."""
+    if not force and not is_stale():
+        return OUT
+    return compile_library(SRC, OUT, extra_flags, verbose)
 
 
 if __name__ == "__main__":

@@ -29,35 +29,11 @@
 #include "../../include/hydro.h"
 #include "hydro_body.h"
 
-#ifndef HYDRO_AB_LDS_WRENCH
-#define HYDRO_AB_LDS_WRENCH 0        // A/B knob, see wrench_tiled_kernel
-#endif
-#ifndef HYDRO_AB_AOS_LDS              // A/B knob: hydro_step_wrench_aos through the LDS-staged wrench_aos_kernel (measured slower)
-#define HYDRO_AB_AOS_LDS 0
-#endif
-#ifndef HYDRO_AB_TILED_LDS            // A/B knob: hydro_step_wrench_tiled through wrench_tiled_lds_kernel (LDS-DMA staging)
-#define HYDRO_AB_TILED_LDS 0
-#endif
-#ifndef HYDRO_AB_XCD_REMAP            // A/B knob: contiguous eighths of the tiles per XCD in wrench_tiled_kernel (measured: see DESIGN.md)
-#define HYDRO_AB_XCD_REMAP 0
-#endif
-#ifndef HYDRO_AB_TILED_WAVES         // A/B knob: minimum resident waves per SIMD asked of the tiled wrench kernel (0 = what it needs)
-#define HYDRO_AB_TILED_WAVES 0
-#endif
-// Default: AT MOST 4 waves per SIMD.  After the instruction diet of round 3 two instantiations of the tiled kernel need
-// only 95 VGPRs and would run 5 waves per SIMD; interleaved A/B on three boxes: the same code at
-// 4 waves is 0.1-0.3 us faster at 1 M bodies (22.31-22.56 vs 22.39-22.86 us) - the fifth wave buys no latency hiding
-// that the kernel lacks and costs a little in the memory system.
-#ifndef HYDRO_AB_TILED_WAVES_MAX
-#define HYDRO_AB_TILED_WAVES_MAX 4
-#endif
-#if HYDRO_AB_TILED_WAVES
-#define HYDRO_TILED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(HYDRO_AB_TILED_WAVES)))
-#elif HYDRO_AB_TILED_WAVES_MAX
-#define HYDRO_TILED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(1, HYDRO_AB_TILED_WAVES_MAX)))
-#else
-#define HYDRO_TILED_OCC_ATTR
-#endif
+// The tiled wrench kernel is built for AT MOST 4 waves per SIMD.  After the instruction diet of round 3 two of its
+// instantiations need only 95 VGPRs and would run 5 waves per SIMD; interleaved A/B on three boxes:
+// the same code at 4 waves is 0.1-0.3 us faster at 1 M bodies (22.31-22.56 vs 22.39-22.86 us) - the fifth wave buys no
+// latency hiding that the kernel lacks and costs a little in the memory system.
+#define HYDRO_TILED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(1, 4)))
 
 namespace {
 
@@ -101,65 +77,25 @@ __device__ __forceinline__ T* at(void* __restrict__ p, uint32_t lane_off, uint32
 
 // NT = streaming access: every byte of a large scene is touched once per step, so nothing is worth keeping in
 // L2 / Infinity Cache: non-temporal loads (measured +5..9 % on the SoA kernel) and write-through stores (below).
-#ifndef HYDRO_AB_LOAD_POLICY          // A/B knob for the streaming loads: 0 = nt (default), 1 = sc1, 2 = sc0 sc1
-#define HYDRO_AB_LOAD_POLICY 0
-#endif
 template <bool NT, typename V>
 __device__ __forceinline__ V ldg(const V* p)
 {
-    if constexpr (NT) {
-#if HYDRO_AB_LOAD_POLICY == 0
-        return __builtin_nontemporal_load(p);
-#else
-        constexpr int scope = HYDRO_AB_LOAD_POLICY == 1 ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_SYSTEM;
-        if constexpr (sizeof(V) == 4 || sizeof(V) == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, scope);
-        else return __builtin_nontemporal_load(p);
-#endif
-    } else return *p;
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 // Streaming STORES are write-through (`sc0 sc1`), not `nt`.  An nt store leaves its line dirty in the XCD's L2 to be
 // written back later (MI355X_MICROARCH.md: "plain / sc0 / nt KEEP the line in L2, sc1 / sc0 sc1 DROP it"); a kernel
 // that writes 24-48 B per body and never reads them again does better handing them straight to the memory side.
 // Measured, sustained over 2 s per variant on two boxes (scripts/ab_sustained.py, C5): nt 22.83-23.09 / 23.5-25.1 us,
 // sc1 21.44 / 22.8-24.0, sc0 sc1 21.36 / 22.15-22.5 us per launch (-6.5 %); 4 M bodies 80.9 -> 79.0 us; identical bits.
-// A/B knob: -DHYDRO_AB_STORE_POLICY=0 (nt) / 1 (sc1) / 2 (sc0 sc1, default).
-#ifndef HYDRO_AB_STORE_POLICY
-#define HYDRO_AB_STORE_POLICY 2
-#endif
-#ifndef HYDRO_AB_WIDE_STORE_WT        // A/B knob: 12- and 16-byte streaming stores write-through too (1, default) or nt (0)
-#define HYDRO_AB_WIDE_STORE_WT 1
-#endif
-// One write-through store of 4, 8, 12 or 16 bytes.  The compiler offers the cache policy only through atomics (4 and 8
-// bytes); the wider ones are spelled out.  Nothing in a kernel reads these addresses back, so the store the compiler
-// cannot see needs no waitcnt of its own ("memory" keeps it ordered against the surrounding accesses).
-// BYTES is spelled out because sizeof() of a 3-vector is 16.
-template <int BYTES, typename V>
-__device__ __forceinline__ void store_write_through(void* p, V v)        // void*: the caller vouches for the alignment
+// One write-through store of 4 or 8 bytes (all the streaming kernels need: one field of one or two bodies per lane).  The
+// compiler offers the cache policy only through atomics.
+template <typename V>
+__device__ __forceinline__ void store_write_through(V* p, V v)
 {
-#if HYDRO_AB_STORE_POLICY == 1
-    constexpr int scope = __HIP_MEMORY_SCOPE_AGENT;
-#else
-    constexpr int scope = __HIP_MEMORY_SCOPE_SYSTEM;
-#endif
-    if constexpr (BYTES == 4) {
-        __hip_atomic_store(static_cast<V*>(p), v, __ATOMIC_RELAXED, scope);
-    } else if constexpr (BYTES == 8) {
-        __hip_atomic_store(static_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, scope);
-    } else if constexpr (BYTES == 12 && HYDRO_AB_WIDE_STORE_WT) {
-#if HYDRO_AB_STORE_POLICY == 1
-        asm volatile("global_store_dwordx3 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-#else
-        asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-#endif
-    } else if constexpr (BYTES == 16 && HYDRO_AB_WIDE_STORE_WT) {
-#if HYDRO_AB_STORE_POLICY == 1
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-#else
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-#endif
-    } else {
-        __builtin_nontemporal_store(v, static_cast<V*>(p));
-    }
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8, "one or two floats");
+    if constexpr (sizeof(V) == 4) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // The simulator-facing AoS kernel is the exception: its 12-byte force / torque rows and its prev-velocity fields measured
 // 2-3 % FASTER as nt stores (27.75 vs 28.32 us at 1 M bodies, 102.0 vs 105.1 us at 4 M), so it stays on stg_nt.
@@ -172,14 +108,8 @@ __device__ __forceinline__ void stg_nt(V* p, V v)
 template <bool NT, typename V>
 __device__ __forceinline__ void stg(V* p, V v)
 {
-    if constexpr (NT) {
-#if HYDRO_AB_STORE_POLICY == 0
-        __builtin_nontemporal_store(v, p);
-#else
-        static_assert(sizeof(V) == 4 || sizeof(V) == 8 || (sizeof(V) == 16 && alignof(V) == 16), "3-vectors go through st_f3_a4");
-        store_write_through<(int)sizeof(V)>(p, v);
-#endif
-    } else *p = v;
+    if constexpr (NT) store_write_through(p, v);
+    else *p = v;
 }
 
 template <int VEC, bool NT>
@@ -237,90 +167,132 @@ __device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t
 
 
 // --------------------------------------------------------------------------
-// kinetic-energy reduction ("wave64 shuffle -> LDS -> one fp64 partial per block -> deterministic second
+// kinetic-energy reduction ("wave64 shuffle/DPP -> LDS -> one fp64 partial per block -> deterministic second
 // stage"), all of it inside ONE launch.
 //
-// The decomposition is the same whether the first stage runs stand-alone (ke_kernel) or inside a wrench / step kernel
-// that has the bodies in registers anyway (their KE template argument) - both give the same bits:
-//   1. bodies are grouped by 256 consecutive indices (4 tiles); lane l of a group adds ITS four bodies - indices
-//      256 g + l, + 64, + 128, + 192 - in that order:   x_l = ((b0 + b1) + b2) + b3   (absent bodies count +0.0);
-//   2. the 64 lane sums go through the wave64 shuffle tree (offsets 32, 16, ... 1) -> partial P_g, stored at partials[g];
-//   3. every block takes a ticket (device-scope atomic); the block that draws the LAST one adds the partials in a fixed
-//      order - thread t of 256 takes t, t + 256, ... in index order, then the shuffle tree per wave, then the four wave
-//      sums in order - and writes the pair.  No second launch (a dependent 1-block launch cost 2-4 us, as much as the
-//      first stage of 500 k bodies), no floating-point atomics, a result that does not depend on which block came last.
-// The ticket counter lives behind the partials ([2][stride] doubles, then one 64-bit slot) and is reset by the block that
-// finishes, so a launch leaves it at 0: launches on one engine must not overlap (a handle is not thread-safe anyway).
+// The first stage is the same code whether it runs stand-alone (ke_kernel) or inside a wrench / step kernel that has the
+// bodies in registers anyway (their KE template argument), so both give the same bits:
+//   1. one block = one GROUP of 256 consecutive bodies, wave w holds tile w in its lanes (a lane without a body holds
+//      +0.0).  The four waves' lane values meet in LDS; lane l of wave 0 adds ITS four bodies in order,
+//      x_l = ((b0 + b1) + b2) + b3, and waves 1-3 are done;
+//   2. wave 0 adds its 64 lane sums (wave_sum below: DPP butterflies inside the rows of 16, then the four rows in order)
+//      -> partial P_g, published at partials[g];
+//   3. groups are dealt to 64 CLASSES round-robin, class(g) = g % 64.  The class sum S_c adds the partials of class c in a
+//      fixed order (lane t of ONE wavefront takes the class's members t, t + 64, t + 128, ... in that order, absent ones as +0.0; then wave_sum), the total adds
+//      S_0 .. S_63 through one more wave_sum.
+// Who does step 3 is decided by TICKETS (integer atomics; no floating-point atomics anywhere): wave 0 of every block
+// draws one from its class's counter, the one that draws a class's last ticket adds that class and draws from the top
+// counter, the one that draws the last of those adds the classes.  Two levels because a device-scope atomic on ONE
+// address costs ~12 ns per ticket, SERIALISED (scripts/ubench_atomics.hip: 48 us for the 4 096 blocks of 1 M bodies on one
+// counter; the same tickets spread over 32 counters cost nothing measurable), and because the final sum is split over up
+// to 64 wavefronts.  The result does not depend on which block draws which ticket.
+// Memory ordering is spelled out for gfx950 rather than asked of the compiler as release / acquire at device scope:
+// a release there is a write-back of the whole L2 (buffer_wbl2; measured 7 ns per fence, serialised over the device - 30 us
+// for the blocks of 1 M bodies) and exists to publish ORDINARY stores.  Here everything that crosses blocks is a
+// device-scope atomic access - write-through stores (sc1), sc1 loads, the tickets - with s_waitcnt vmcnt(0) between a
+// wave's stores and its ticket ("complete" at device scope), and the few wavefronts that read what others wrote
+// invalidate their non-coherent caches first (one buffer_inv per finisher: at most 65 per launch).
+// What the tail costs: ~0.75 us per ticket whose result is waited for, ~0.2 us per published value, i.e. ~2.5 us after the
+// last block's bodies have arrived; a second launch for the final sum cost 4 us.
+// The counters are reset by the wavefronts that finish, so a launch leaves them at 0: launches on one engine must not
+// overlap (a handle is not thread-safe anyway).
+// Scratch (doubles): [stride] translational partials | [stride] rotational | [64] + [64] class sums | counters (uint32, one
+// per 256 B): top, class 0 .. 63.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double x)
+constexpr uint32_t kKeClasses = 64;
+constexpr size_t kKeScratchTailBytes = 2 * kKeClasses * sizeof(double) + (1 + kKeClasses) * 256;
+
+// Sum over the 64 lanes of a wavefront, the same bits in whatever order the hardware runs: inside each row of 16 lanes
+// four butterfly steps on DPP moves (lane ^ 1, lane ^ 2, mirror of 8, mirror of 16: a + b == b + a, so every lane of a
+// row ends up with the same row sum), then the four row sums in order, ((r0 + r1) + r2) + r3, read with v_readlane.
+// ~25 instructions and no LDS round trips (the ds_bpermute tree it replaces: twelve dependent ones for a pair).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
+    const uint64_t u = __builtin_bit_cast(uint64_t, x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double read_lane(double x, int lane)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum(double x)          // every lane of the wavefront must be active
+{
+    x += dpp_move<0xB1>(x);        // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);        // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);       // row_half_mirror
+    x += dpp_move<0x140>(x);       // row_mirror
+    return ((read_lane(x, 0) + read_lane(x, 16)) + read_lane(x, 32)) + read_lane(x, 48);
+}
+__device__ __forceinline__ void ke_publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ke_fetch(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lane 0 draws a ticket; every lane gets its number
+__device__ __forceinline__ uint32_t ke_ticket(uint32_t* counter)
+{
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+__device__ __forceinline__ void ke_reset(uint32_t* counter)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Step 2 for ONE wavefront holding the 64 lane sums of group `group`: tree, lane 0 stores the partial write-through at
-// device scope (the block that finishes may run on another XCD, behind another L2).
-__device__ __forceinline__ void ke_store_partial(double lin, double rot, uint32_t group, double* __restrict__ partials, uint32_t stride)
-{
-    lin = wave_sum(lin);
-    rot = wave_sum(rot);
-    if ((threadIdx.x & 63u) == 0) {
-        __hip_atomic_store(partials + group, lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(partials + stride + group, rot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Step 3.  Every thread of a 256-thread block calls this after the block's partials have been stored (by ke_store_partial,
-// in any of its waves).  `groups` = number of partials of the launch; the launch has gridDim.x blocks.
-__device__ __forceinline__ void ke_finish_block(double* __restrict__ partials, uint32_t stride, uint32_t groups, double* __restrict__ out)
-{
-    __shared__ uint32_t last_block;
-    __shared__ double red[2][kBlock / 64];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this wave's partial is on its way to memory ...
-    __syncthreads();                                            // ... and so are the other waves'
-    if (threadIdx.x == 0) {
-        uint32_t* counter = reinterpret_cast<uint32_t*>(partials + 2 * (size_t)stride);
-        const uint32_t ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_block = (ticket == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!last_block) return;                                     // (uniform over the block)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double l = 0.0, r = 0.0;
-#pragma unroll 8
-    for (uint32_t k = threadIdx.x; k < groups; k += kBlock) {
-        l += __hip_atomic_load(partials + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r += __hip_atomic_load(partials + stride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    l = wave_sum(l);
-    r = wave_sum(r);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = l; red[1][wave] = r; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        out[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        out[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(partials + 2 * (size_t)stride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// The form the wrench / step kernels use: one block = one group, wave w holds tile w in its lanes.  Step 1 goes through
-// LDS (the four waves' lane values side by side), wave 0 does step 2, everybody step 3.  Every thread of the block calls
-// this (lanes without a body with zeros).
-__device__ __forceinline__ void ke_block_reduce(double lin, double rot, double* __restrict__ partials, uint32_t stride, double* __restrict__ out)
+// Every thread of a 256-thread block calls this with the kinetic energy of its body (zeros for a lane without one).
+// `groups` == gridDim.x.
+__device__ __forceinline__ void ke_block_reduce(double lin, double rot, double* __restrict__ scratch, uint32_t stride, double* __restrict__ out)
 {
     __shared__ double stage[2][kBlock];
     stage[0][threadIdx.x] = lin;
     stage[1][threadIdx.x] = rot;
     __syncthreads();
-    if (threadIdx.x < 64u) {
-        const uint32_t l = threadIdx.x;
-        const double a = ((stage[0][l] + stage[0][64 + l]) + stage[0][128 + l]) + stage[0][192 + l];
-        const double b = ((stage[1][l] + stage[1][64 + l]) + stage[1][128 + l]) + stage[1][192 + l];
-        ke_store_partial(a, b, blockIdx.x, partials, stride);
+    if (threadIdx.x >= 64u) return;                              // waves 1-3 are done
+    // ---- wave 0, all 64 lanes, no barrier from here on ----
+    const uint32_t l = threadIdx.x, group = blockIdx.x, groups = gridDim.x;
+    double a = ((stage[0][l] + stage[0][64 + l]) + stage[0][128 + l]) + stage[0][192 + l];       // step 1
+    double b = ((stage[1][l] + stage[1][64 + l]) + stage[1][128 + l]) + stage[1][192 + l];
+    a = wave_sum(a);                                                                             // step 2
+    b = wave_sum(b);
+    if (l == 0) { ke_publish(scratch + group, a); ke_publish(scratch + stride + group, b); }
+    double* class_sums = scratch + 2 * (size_t)stride;
+    uint32_t* counters = reinterpret_cast<uint32_t*>(class_sums + 2 * kKeClasses);
+    const uint32_t cls = group % kKeClasses;
+    const uint32_t members = (groups - cls + kKeClasses - 1u) / kKeClasses;                      // groups g < groups with g % 64 == cls
+    __builtin_amdgcn_s_waitcnt(0);                               // the partial is complete at device scope before the ticket goes out
+    if (ke_ticket(counters + 64u * (1u + cls)) != members - 1u) return;
+    // ---- the last ticket of the class: S_cls (step 3, first half) ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    a = 0.0; b = 0.0;
+    for (uint32_t e0 = 0; e0 < members; e0 += 256u) {           // four members per lane in flight (4 M bodies: one round)
+        double pa[4], pb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = e0 + 64u * k + l;
+            pa[k] = e < members ? ke_fetch(scratch + cls + kKeClasses * e) : 0.0;
+            pb[k] = e < members ? ke_fetch(scratch + stride + cls + kKeClasses * e) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a += pa[k]; b += pb[k]; }
     }
-    ke_finish_block(partials, stride, gridDim.x, out);
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (l == 0) { ke_publish(class_sums + cls, a); ke_publish(class_sums + kKeClasses + cls, b); }
+    ke_reset(counters + 64u * (1u + cls));
+    const uint32_t classes = groups < kKeClasses ? groups : kKeClasses;
+    __builtin_amdgcn_s_waitcnt(0);
+    if (ke_ticket(counters) != classes - 1u) return;
+    // ---- and the last ticket of all: the total ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    a = l < classes ? ke_fetch(class_sums + l) : 0.0;
+    b = l < classes ? ke_fetch(class_sums + kKeClasses + l) : 0.0;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (l == 0) { out[0] = a; out[1] = b; }
+    ke_reset(counters);
 }
 
 // --------------------------------------------------------------------------
@@ -416,17 +388,6 @@ __global__ void __launch_bounds__(BLOCK) wrench_soa_kernel(const SoaArgs a)
     }
 }
 
-// Wave-private staging: each wavefront transposes ITS 64 bodies through its own LDS slice (positions
-// 768 B, velocities 1536 B in; forces + torques 1536 B out), so no workgroup barrier is needed at all.
-// LDS operations of one wave execute in order; what has to be prevented is the COMPILER moving a lane's
-// reads above other lanes' writes (per thread the addresses differ), hence the wavefront-scope fences.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // --------------------------------------------------------------------------
 // fused wrench, TILED struct-of-arrays (the engine's native layout).
 //
@@ -501,16 +462,7 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pv_out; a.pvo_stride = pvo_stride;
     a.prm = k_prm; a.out = k_out; a.out_stride = out_stride; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = warp; a.n = n;
-#if HYDRO_AB_XCD_REMAP
-    // A/B arm: blocks are handed to the 8 XCDs round-robin; give XCD x the x-th contiguous eighth of
-    // the tiles instead of every eighth block.  Nothing is shared between blocks, so this only changes which DRAM pages the
-    // eight L2s stream from at a given moment.
-    const uint32_t per_xcd = (gridDim.x + 7u) >> 3;
-    const uint32_t bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const uint32_t i = (bid < gridDim.x ? bid : blockIdx.x) * BLOCK + threadIdx.x;       // (exact when gridDim.x % 8 == 0, as in the A/B)
-#else
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-#endif
     if constexpr (!KE) {
         if (i >= a.n) return;
     }
@@ -526,25 +478,9 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
         if constexpr (KE)
             hydro::kinetic_energy(s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], d[0], d[1], d[2], mass,
                                   ke_rotational != 0, ke_lin, ke_rot);
-#if HYDRO_AB_LDS_WRENCH
-        // A/B knob ("LDS staging"): the wave's 6 x 256 B of wrench go through a wave-private LDS slice
-        // and leave as 1.5 sixteen-byte stores per lane instead of six four-byte ones.  Measured: no faster - the
-        // four-byte stores of a wave already cover whole 256-B runs.
-        {
-            __shared__ __attribute__((aligned(16))) float stage[BLOCK / 64][6 * 64];
-            using f4 = float __attribute__((ext_vector_type(4)));
-            float* sl = stage[threadIdx.x >> 6];
-            sl[lane] = w.fx; sl[64 + lane] = w.fy; sl[128 + lane] = w.fz; sl[192 + lane] = w.tx; sl[256 + lane] = w.ty; sl[320 + lane] = w.tz;
-            wave_lds_fence();
-            f4* dst = reinterpret_cast<f4*>(const_cast<float*>(a.out) + (size_t)__umul24(tile, a.out_stride));
-            stg<NT>(dst + lane, reinterpret_cast<const f4*>(sl)[lane]);
-            if (lane < 32u) stg<NT>(dst + 64 + lane, reinterpret_cast<const f4*>(sl)[64 + lane]);
-        }
-#else
         const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
         stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
         stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
-#endif
         if constexpr (WRITE_PREV) {
             const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
 #pragma unroll
@@ -556,13 +492,6 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
         ke_block_reduce(ke_lin, ke_rot, ke_partials, ke_stride, ke_out);
     }
 }
-
-#ifndef HYDRO_AB_TILED_PIPE           // A/B arm: tiles per wave of the software-pipelined kernel (0 = not used)
-#define HYDRO_AB_TILED_PIPE 0
-#endif
-#if HYDRO_AB_TILED_PIPE || HYDRO_AB_TILED_LDS
-#include "hydro_ab_tiled_arms.h"      // the measured-and-rejected forms of the tiled kernel, compiled out of the product
-#endif
 
 // Parameters: the caller's 11 field arrays -> the engine's tiled records (once per hydro_set_params_*), and back into
 // plain-SoA copies for the entry points that take plain field pointers (made on their first use only).
@@ -713,14 +642,8 @@ struct AosArgs {
 // up with conflict-free strides, three wavefront fences): 30.3 vs 34.0 us at 1 M bodies, 111.6 vs 113.7 us at 4 M,
 // identical bits; 91 % / 100 % of a memory-only probe of the same traffic (scripts/probes.py).
 // --------------------------------------------------------------------------
-#ifndef HYDRO_AB_AOS_STORE_WT         // A/B knob: write-through stores in the AoS kernel too (measured slower, see stg_nt)
-#define HYDRO_AB_AOS_STORE_WT 0
-#endif
 template <bool NT, typename V>
-__device__ __forceinline__ void stg_aos(V* p, V v)
-{
-    if constexpr (HYDRO_AB_AOS_STORE_WT) stg<NT>(p, v); else stg_nt<NT>(p, v);
-}
+__device__ __forceinline__ void stg_aos(V* p, V v) { stg_nt<NT>(p, v); }
 typedef float f3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
@@ -731,7 +654,7 @@ typedef float f4_a16 __attribute__((ext_vector_type(4), aligned(16)));
     { const T* q = reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off); if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; } \
     template <bool NT> __device__ __forceinline__ void st_##T(void* base, uint32_t byte_off, T v)                            \
     { T* q = reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);                                                      \
-      if constexpr (!NT) *q = v; else if constexpr (!HYDRO_AB_AOS_STORE_WT) __builtin_nontemporal_store(v, q); else store_write_through<BYTES>(q, v); }
+      if constexpr (NT) __builtin_nontemporal_store(v, q); else *q = v; }
 HYDRO_WIDE_ACCESS(f3_a4, 12)
 HYDRO_WIDE_ACCESS(f4_a8, 16)
 HYDRO_WIDE_ACCESS(f2_a8, 8)
@@ -749,13 +672,10 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
     // The simulator's rows are read with TEMPORAL loads whatever the size: the simulator has just written them, so they
     // are the one input that can still be in L2 / the Infinity Cache (the engine's own records and the outputs stream).
-    // Measured (A/B, -DHYDRO_AB_AOS_ROWS_NT=1 for the streaming arm): equal when nothing can be resident (8 rotating sets
+    // Measured (A/B against a build whose row loads stream too): equal when nothing can be resident (8 rotating sets
     // of 1 M bodies: 29.84 vs 29.96 us; 4 M: 112.2 vs 112.3), 12 % faster when the rows are (4 sets: 26.5 vs 30.2 us) -
     // which is also why bench.py rotates EIGHT sets for this entry: its figure must be an HBM rate.
-#ifndef HYDRO_AB_AOS_ROWS_NT
-#define HYDRO_AB_AOS_ROWS_NT 0
-#endif
-    constexpr bool RNT = NT && (HYDRO_AB_AOS_ROWS_NT != 0);
+    constexpr bool RNT = false;
     const f3_a4 p = ld_f3_a4<RNT>(k_pos, i * 12u);
     const f4_a16 q = ld_f4_a16<RNT>(k_quat, i * 16u);
     const f4_a8 v0 = ld_f4_a8<RNT>(k_vel, i * 24u);
@@ -791,10 +711,6 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
     st_f3_a4<NT>(k_force, i * 12u, fo);
     st_f3_a4<NT>(k_torque, i * 12u, to);
 }
-
-#if HYDRO_AB_AOS_LDS
-#include "hydro_ab_aos_arm.h"         // the LDS-staged form of this entry (measured slower), compiled out of the product
-#endif
 
 // --------------------------------------------------------------------------
 // component mode (compatibility / debug surface, not a benchmark mode)
@@ -890,11 +806,13 @@ __global__ void __launch_bounds__(kBlock) components_aos_kernel(const CompAosArg
 
 // --------------------------------------------------------------------------
 // kinetic energy, stand-alone (hydro_kinetic_energy[_tiled]): one pass over 56 B per body with the rotational term (40
-// of the 52 state bytes + dimensions and mass), 20 B without - a pure streaming kernel, HBM-bound.
-// A WAVEFRONT takes one group of 256 consecutive bodies = four tiles: all its 44 (16) loads are issued before the first
-// use, so a wave has 11 KB in flight and its one shuffle tree is paid per 256 bodies, not per 64; the four waves of a
-// block share nothing until the ticket (ke_finish_block).  State from plain SoA field pointers or from a tiled buffer
-// (one address rule, see IntArgs); dimensions and mass from the engine's tiled parameter record.
+// of the 52 state bytes + dimensions and mass), 20 B without - a pure streaming kernel, HBM-bound, in the shape of the
+// in-kernel sampling: one body per lane, every load issued before the first use, one group per block.  (Measured against
+// a wavefront per group - four tiles per lane, 44 loads in flight, no LDS: 12.1 vs 11.05 us at 1 M bodies and 37.1 vs
+// 35.6 us at 4 M before the final sum; the memory-only probe of the same bytes takes 9.9 / 35.3 us.  Many short waves
+// overlap one wave's arithmetic with the others' loads; few long ones do all their arithmetic after their data.)
+// State from plain SoA field pointers or from a tiled buffer (one address rule, see IntArgs); dimensions and mass from the
+// engine's tiled parameter record.
 // --------------------------------------------------------------------------
 struct KeArgs {
     const float* st[HYDRO_STATE_FIELDS];   // plain SoA field pointers, or tiled base + f*64
@@ -909,46 +827,26 @@ struct KeArgs {
 template <bool ROT>
 __global__ void __launch_bounds__(kBlock) ke_kernel(const KeArgs a)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t groups = (a.n + 255u) >> 8;
-    const uint32_t group = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (group < groups) {                                        // (uniform over the wave; no return: the block meets again below)
-        float m[4], v[3][4], q[4][4], w[3][4], d[3][4];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    double lin = 0.0, rot = 0.0;
+    if (i < a.n) {
+        // state: field base pointers in SGPRs + one 32-bit byte offset (i < 2^30; tiled buffers < 4 GiB);
+        // parameter record: one 64-bit address, field offsets in the instruction
+        const uint32_t o = ((i >> a.shift) * a.st_stride + (i & a.mask)) * 4u;
+        const float* pr = a.prm + (size_t)(i >> 6) * a.prm_tile_floats + (i & 63u);
+        const float m = __builtin_nontemporal_load(pr + a.mass_field * 64u);
+        float v[3], q[4] = {0.f, 0.f, 0.f, 1.f}, w[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t i = (group << 8) + t * 64u + lane;
-            m[t] = 0.f;
+        for (int k = 0; k < 3; ++k) v[k] = ldg<true>(at<float>(a.st[7 + k], o));
+        if constexpr (ROT) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { v[k][t] = 0.f; w[k][t] = 0.f; d[k][t] = 0.f; }
-            q[0][t] = q[1][t] = q[2][t] = 0.f; q[3][t] = 1.f;
-            if (i < a.n) {                                       // (a body that is not there adds +0.0)
-                // state: field base pointers in SGPRs + one 32-bit byte offset (i < 2^30; tiled buffers < 4 GiB);
-                // parameter record: one 64-bit address per tile, field offsets in the instruction
-                const uint32_t o = ((i >> a.shift) * a.st_stride + (i & a.mask)) * 4u;
-                const float* pr = a.prm + (size_t)(i >> 6) * a.prm_tile_floats + lane;
-                m[t] = __builtin_nontemporal_load(pr + a.mass_field * 64u);
+            for (int k = 0; k < 4; ++k) q[k] = ldg<true>(at<float>(a.st[3 + k], o));
 #pragma unroll
-                for (int k = 0; k < 3; ++k) v[k][t] = ldg<true>(at<float>(a.st[7 + k], o));
-                if constexpr (ROT) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) q[k][t] = ldg<true>(at<float>(a.st[3 + k], o));
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { w[k][t] = ldg<true>(at<float>(a.st[10 + k], o)); d[k][t] = __builtin_nontemporal_load(pr + k * 64); }
-                }
-            }
+            for (int k = 0; k < 3; ++k) { w[k] = ldg<true>(at<float>(a.st[10 + k], o)); d[k] = __builtin_nontemporal_load(pr + k * 64); }
         }
-        double lin = 0.0, rot = 0.0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            double l, r;
-            hydro::kinetic_energy(q[0][t], q[1][t], q[2][t], q[3][t], v[0][t], v[1][t], v[2][t], w[0][t], w[1][t], w[2][t],
-                                  d[0][t], d[1][t], d[2][t], m[t], ROT, l, r);
-            lin = t ? lin + l : l;
-            rot = t ? rot + r : r;
-        }
-        ke_store_partial(lin, rot, group, a.partials, a.partial_stride);
+        hydro::kinetic_energy(q[0], q[1], q[2], q[3], v[0], v[1], v[2], w[0], w[1], w[2], d[0], d[1], d[2], m, ROT, lin, rot);
     }
-    ke_finish_block(a.partials, a.partial_stride, groups, a.out);
+    ke_block_reduce(lin, rot, a.partials, a.partial_stride, a.out);
 }
 
 // --------------------------------------------------------------------------
@@ -1558,9 +1456,10 @@ int hydro_create(int device, int64_t capacity, hydro_t** out)
     ok = ok && hipMalloc(&h->params_tiled, fbytes * HYDRO_PARAM_FIELDS) == hipSuccess;
     ok = ok && hipMalloc(&h->prev_tiled, fbytes * HYDRO_PREV_FIELDS) == hipSuccess;
     ok = ok && hipMemsetAsync(h->prev_tiled, 0, fbytes * HYDRO_PREV_FIELDS, h->stream) == hipSuccess;
-    // [2][ke_stride] partials + the ticket counter of the reduction (zero between launches, see ke_finish_block)
-    ok = ok && hipMalloc(&h->ke_partials, sizeof(double) * (2 * (size_t)h->ke_stride + 1)) == hipSuccess;
-    ok = ok && hipMemsetAsync(h->ke_partials, 0, sizeof(double) * (2 * (size_t)h->ke_stride + 1), h->stream) == hipSuccess;
+    // [2][ke_stride] partials + class sums and ticket counters of the reduction (zero between launches, see ke_finish_block)
+    const size_t ke_bytes = sizeof(double) * 2 * (size_t)h->ke_stride + kKeScratchTailBytes;
+    ok = ok && hipMalloc(&h->ke_partials, ke_bytes) == hipSuccess;
+    ok = ok && hipMemsetAsync(h->ke_partials, 0, ke_bytes, h->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
     if (!ok) { hydro_destroy(h); return HYDRO_E_ALLOC; }
     *out = h;
@@ -1762,21 +1661,8 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
 #define HYDRO_TILED_NT(BLOCK, HALF, WP) do { if (nt) HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, true); else HYDRO_TILED_LAUNCH(BLOCK, HALF, WP, false); } while (0)
 #define HYDRO_TILED_WP(BLOCK, HALF) do { if (own_prev) HYDRO_TILED_NT(BLOCK, HALF, true); else HYDRO_TILED_NT(BLOCK, HALF, false); } while (0)
 #define HYDRO_TILED_HALF(BLOCK) do { if (h->half_coeffs) HYDRO_TILED_WP(BLOCK, true); else HYDRO_TILED_WP(BLOCK, false); } while (0)
-#if HYDRO_AB_TILED_LDS
-    {
-        const dim3 g256(grid_for(n, kBlock)), b256(kBlock);
-#define HYDRO_LDS_LAUNCH(HALF, WP, NT) hipLaunchKernelGGL((wrench_tiled_lds_kernel<HALF, WP, NT>), g256, b256, 0, s, \
-        a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, a.warp, a.rho, a.g, a.inv_dt)
-#define HYDRO_LDS_NT(HALF, WP) do { if (nt) HYDRO_LDS_LAUNCH(HALF, WP, true); else HYDRO_LDS_LAUNCH(HALF, WP, false); } while (0)
-#define HYDRO_LDS_WP(HALF) do { if (own_prev) HYDRO_LDS_NT(HALF, true); else HYDRO_LDS_NT(HALF, false); } while (0)
-        if (h->half_coeffs) HYDRO_LDS_WP(true); else HYDRO_LDS_WP(false);
-#undef HYDRO_LDS_WP
-#undef HYDRO_LDS_NT
-#undef HYDRO_LDS_LAUNCH
-    }
-#else
     if (ke_out) {
-        // the sampling variant: same body, same bits, plus one fp64 pair per block; then the fixed-order second stage
+        // the sampling variant: same body, same bits, plus one fp64 pair per block and the fixed-order final sum (same launch)
 #define HYDRO_TILED_KE_W(HALF, WP, WARP) do { if (nt) hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, true, true, WARP>), grid, blk, lds, s, HYDRO_TILED_ARGS); \
                                               else hipLaunchKernelGGL((wrench_tiled_kernel<256, HALF, WP, false, true, WARP>), grid, blk, lds, s, HYDRO_TILED_ARGS); } while (0)
 #define HYDRO_TILED_KE(HALF, WP) do { if (a.warp) HYDRO_TILED_KE_W(HALF, WP, true); else HYDRO_TILED_KE_W(HALF, WP, false); } while (0)
@@ -1785,24 +1671,7 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
 #undef HYDRO_TILED_KE
 #undef HYDRO_TILED_KE_W
     }
-#if HYDRO_AB_TILED_PIPE
-    else if (n >= (int64_t)HYDRO_AB_TILED_PIPE * 1024 * HYDRO_AB_PIPE_WAVES * 64) {
-        const uint32_t tiles = (uint32_t)((n + 63) / 64);
-        uint32_t pblocks = (tiles + 4u * HYDRO_AB_TILED_PIPE - 1u) / (4u * HYDRO_AB_TILED_PIPE);
-        const uint32_t wstride = pblocks * 4u;
-#define HYDRO_PIPE_LAUNCH(HALF, WP, NT, W) hipLaunchKernelGGL((wrench_tiled_pipe_kernel<HALF, WP, NT, W>), dim3(pblocks), dim3(kBlock), 0, s, \
-        a.st, a.pv, a.prm, a.out, a.pv_out, a.st_stride, a.pv_stride, a.out_stride, a.pvo_stride, a.n, tiles, wstride, (uint32_t)HYDRO_AB_TILED_PIPE, a.rho, a.g, a.inv_dt)
-#define HYDRO_PIPE_W(HALF, WP, NT) do { if (a.warp) HYDRO_PIPE_LAUNCH(HALF, WP, NT, true); else HYDRO_PIPE_LAUNCH(HALF, WP, NT, false); } while (0)
-#define HYDRO_PIPE_NT(HALF, WP) do { if (nt) HYDRO_PIPE_W(HALF, WP, true); else HYDRO_PIPE_W(HALF, WP, false); } while (0)
-        if (h->half_coeffs) { if (own_prev) HYDRO_PIPE_NT(true, true); else HYDRO_PIPE_NT(true, false); }
-        else { if (own_prev) HYDRO_PIPE_NT(false, true); else HYDRO_PIPE_NT(false, false); }
-#undef HYDRO_PIPE_NT
-#undef HYDRO_PIPE_W
-#undef HYDRO_PIPE_LAUNCH
-    }
-#endif
     else if (block == 128) HYDRO_TILED_HALF(128); else HYDRO_TILED_HALF(256);
-#endif
 #undef HYDRO_TILED_HALF
 #undef HYDRO_TILED_WP
 #undef HYDRO_TILED_NT
@@ -2036,21 +1905,11 @@ int hydro_step_wrench_aos(hydro_t* h, int64_t n, const float* positions, const f
     const int grid = grid_for(n, kBlock);
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
 #define HYDRO_AOS_ARGS a.pos, a.quat, a.vel, a.force, a.torque, a.pv, a.prm, a.quat_xyzw, (uint32_t)a.n, a.warp, a.rho, a.g, a.inv_dt
-#if !HYDRO_AB_AOS_LDS
 #define HYDRO_AOS_W(HALF, NT) do { if (a.warp) hipLaunchKernelGGL((wrench_aos_direct_kernel<HALF, NT, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS); \
                                    else hipLaunchKernelGGL((wrench_aos_direct_kernel<HALF, NT, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS); } while (0)
     if (h->half_coeffs) { if (nt) HYDRO_AOS_W(true, true); else HYDRO_AOS_W(true, false); }
     else { if (nt) HYDRO_AOS_W(false, true); else HYDRO_AOS_W(false, false); }
 #undef HYDRO_AOS_W
-#else
-    if (h->half_coeffs) {
-        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<true, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-        else hipLaunchKernelGGL((wrench_aos_kernel<true, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-    } else {
-        if (nt) hipLaunchKernelGGL((wrench_aos_kernel<false, true>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-        else hipLaunchKernelGGL((wrench_aos_kernel<false, false>), dim3(grid), dim3(kBlock), 0, s, HYDRO_AOS_ARGS);
-    }
-#endif
 #undef HYDRO_AOS_ARGS
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
@@ -2087,7 +1946,7 @@ static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, doub
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) return ke_of_nothing(h, out_dev, s);
-    const dim3 grid(grid_for(n, kBlock * 4)), blk(kBlock);       // a wavefront per 256 bodies, four of them per block
+    const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
     if (rotational) hipLaunchKernelGGL(ke_kernel<true>, grid, blk, 0, s, a);
     else hipLaunchKernelGGL(ke_kernel<false>, grid, blk, 0, s, a);
     HYDRO_HIP(h, hipGetLastError(), HYDRO_E_LAUNCH);

@@ -397,6 +397,32 @@ def test_kinetic_energy_single_launch_reduction_is_order_independent_and_replaya
     eng.close()
 
 
+def test_kinetic_energy_sees_every_update_of_the_state(native_built):
+    """The reduction's partials and class sums cross blocks (and XCDs, each behind its own L2) through device-scope
+    accesses within one launch.  A stale value anywhere would go unnoticed while the state stays the same from launch to
+    launch - here it changes before every launch (300 launches, two sizes alternating on two engines), and every result
+    must be the fp64 sum of THAT state to 1e-12."""
+    sc = scenes.scene_c4(n=65536, seed=17)
+    engines = []
+    for n in (1048576, 300000):
+        reps = -(-n // sc.n)
+        state = np.tile(sc.state, (reps, 1))[:n]; params = np.tile(sc.params, (reps, 1))[:n]
+        eng = HydroEngine(n, DEV, sc.rho, sc.g)
+        eng.set_params(params)
+        st = tiled(state)
+        mass = torch.from_numpy(params[:, 10].astype(np.float64)).to(DEV)
+        engines.append((eng, st, mass, n))
+    for it in range(300):
+        eng, st, mass, n = engines[it % 2]
+        st[:, 7:10, :] *= (1.003 if it % 3 else 0.99)                  # new velocities -> every partial changes
+        ke = eng.kinetic_energy(st, rotational=False)
+        v = st[:, 7:10, :].permute(1, 0, 2).reshape(3, -1)[:, :n].double()
+        want = (0.5 * mass * (v * v).sum(0)).sum().item()
+        assert ke[0].item() == pytest.approx(want, rel=1e-12), it
+    for eng, *_ in engines:
+        eng.close()
+
+
 def test_engine_holds_68_bytes_per_body_until_a_plain_soa_entry_is_used(native_built):
     """The engine's own buffers: tiled parameters (44 B) + tiled previous velocity (24 B) per body of capacity.  The
     plain-SoA copies (82 B more) appear with the first call of an entry point that takes plain field pointers."""
