@@ -289,6 +289,52 @@ def quick_rate(kind: str, n: int, coeff: str, dev, stream, steps: int = 60, sets
             "algorithmic_gbs": sc.n * BYTES_PER_BODY[coeff] / (us * 1e-6) / 1e9, **residency(sc.n, coeff, sets)}
 
 
+def batch_rate(kind: str, n: int, coeff: str, dev, stream, scenes_per_launch: int = 4, sets: int = 2, steps: int = 100, seed: int = 11):
+    """NOT the headline protocol: `scenes_per_launch` independent scenes of n bodies stepped by ONE launch
+    (hydro_step_wrench_tiled_batch), `sets` such groups rotating; beside it the same scenes as single launches, one
+    after the other on the same stream.  Same bits either way (tests/test_parity_gpu.py); the difference is the ramp
+    and drain a launch pays once instead of `scenes_per_launch` times.  HIP events on the launch stream."""
+    sc = build_scene(kind, n, seed)
+    k = scenes_per_launch
+    groups = [[Replica(sc, coeff, dev, roll=(g * k + j) * 97) for j in range(k)] for g in range(sets)]
+    with torch.cuda.stream(stream):
+        batched = [HydroEngine.prepare_step_wrench_tiled_batch([r.engine for r in grp], [r.state for r in grp], sc.dt,
+                                                               outs=[r.out for r in grp], prevs=[r.prev for r in grp])[0] for grp in groups]
+        for grp in groups:
+            for r in grp:
+                r.step()
+        spin_up([r for grp in groups for r in grp], stream, 0.15)
+
+        def timed(fn):
+            for w in range(10):
+                fn(w)
+            samples = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for it in range(steps):
+                    fn(it)
+                e1.record(stream)
+                stream.synchronize()
+                samples.append(e0.elapsed_time(e1) * 1e3 / steps)
+            return sorted(samples)[len(samples) // 2]
+
+        def singles(it):
+            for r in groups[it % sets]:
+                r.step()
+        us_single = timed(singles)
+        us_batch = timed(lambda it: batched[it % sets]())
+    for grp in groups:
+        for r in grp:
+            r.engine.close()
+    per = k * sc.n * BYTES_PER_BODY[coeff]
+    return {"n_per_scene": sc.n, "scenes_per_launch": k, "coeff": coeff, "rotating_groups": sets,
+            "us_per_group_as_single_launches": us_single, "us_per_group_one_launch": us_batch,
+            "frac_single_launches": per / (us_single * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_one_launch": per / (us_batch * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "body_steps_per_s_one_launch": k * sc.n / (us_batch * 1e-6), **residency(sc.n, coeff, sets * k)}
+
+
 def two_stream_rate(kind: str, n: int, coeff: str, dev, steps: int = 400, sets: int = 4, seed: int = 11):
     """NOT the headline protocol: the rotating replicas are independent scenes; stepped round-robin on TWO streams (even /
     odd replicas) the drain of one launch overlaps the ramp of the next.  The difference to the one-stream figure of the
@@ -420,6 +466,44 @@ def aos_rate(n: int, dev, stream, steps: int = 100, sets: int = 8, seed: int = 1
             **residency(sc.n, "f32", sets, 12 + 16 + 24 + 24 + 24 + 44)}
 
 
+# VALU-issue roofline of the compute-bound path (the resident closed loop never touches HBM between steps).
+# A SIMD (16 lanes) issues one wave64 VALU instruction per 4 cycles: 1 024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions / s
+# for 4-cycle instructions.  What an instruction class actually costs was measured (scripts/ubench_valu.hip, 4 and 8 waves
+# per SIMD, clock read in-kernel): fp64 arithmetic 4.2 cycles, fp32 arithmetic 2.7, everything else
+# the body is made of (conversions, selects, bit operations, compares, the transcendental seeds) ~4.
+VALU_ISSUE_CYCLES = {"fp64 arithmetic": 4.2, "fp32 arithmetic": 2.7, "conversion": 4.0, "compare": 4.0,
+                     "integer / select / move": 4.0, "transcendental": 4.0}
+SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4
+
+
+def valu_roofline(kernel_prefix: str, n: int, us_per_step: float, clock_held_ghz: float | None = None):
+    """{"bound": "valu-issue", ...} for one step of a kernel whose instruction mix scripts/isa_mix.py recorded
+    (profiles/isa_mix.json; tests/test_isa_budget.py keeps it current): issue cycles of the step's VALU instructions,
+    priced per class, over the cycles the SIMDs had - at the 2.4 GHz peak clock (`frac`) and at the clock the chip held."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "isa_mix.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    key = next((k for k in kernels if k.startswith(kernel_prefix)), None)
+    if key is None:
+        return None
+    mix = kernels[key]["valu_by_class"]
+    cycles = sum(VALU_ISSUE_CYCLES[c] * k for c, k in mix.items())
+    waves_per_simd = -(-n // 64) / SIMDS
+    busy_us_at_peak = cycles * waves_per_simd / (PEAK_CLOCK_GHZ * 1e3)
+    out = {"bound": "valu-issue", "kernel": key, "valu_instructions_per_body_step": kernels[key]["valu_total"],
+           "valu_by_class": mix, "issue_cycles_per_wave_step": cycles, "waves_per_simd": waves_per_simd,
+           "achieved": kernels[key]["valu_total"] * (n / 64) / (us_per_step * 1e-6) / 1e9,
+           "peak": SIMDS * PEAK_CLOCK_GHZ / 4.0, "unit": "G wave-instructions/s (peak: 4-cycle instructions at 2.4 GHz)",
+           "frac": busy_us_at_peak / us_per_step,
+           "frac_is": "issue cycles of the step's VALU instructions (priced per class) / cycles of 1 024 SIMDs at 2.4 GHz in the measured time"}
+    if clock_held_ghz:
+        out["clock_held_ghz"] = clock_held_ghz
+        out["frac_at_clock_held"] = busy_us_at_peak * PEAK_CLOCK_GHZ / clock_held_ghz / us_per_step
+    return out
+
+
 def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, implicit_drag: bool = False, resident: bool = False):
     """Wrench + integrator ping-pong replayed from a HIP graph (simulate.ClosedLoopSim); RTF as
     benchmark_rtf.py defines it (sim time / wall time).  fused: one kernel per physics step
@@ -435,7 +519,12 @@ def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, i
     if implicit_drag:
         mode += ", implicit drag"
     # ONE scene stepping on itself: state ping-pong (2 x 52 B) + parameters
-    return {"n": n, "mode": mode, **r, **residency(n, "f32", 1, 2 * 52 + 44)}
+    out = {"n": n, "mode": mode, **r, **residency(n, "f32", 1, 2 * 52 + 44)}
+    if resident:          # compute-bound (no HBM traffic between the steps): its roofline is VALU issue, not bytes
+        vr = valu_roofline("resident closed loop, one step, implicit drag" if implicit_drag else "resident closed loop, one step (", n, r["us_per_step"])
+        if vr:
+            out["roofline"] = vr
+    return out
 
 
 def roofline_4m(dev, stream, coeff: str = "f16", n: int = 4194304, sets: int = 2, steps: int = 200):
@@ -966,6 +1055,7 @@ def main():
             guarded("c5_f32_1048576", quick_rate, "c4", 1048576, "f32", dev, stream, steps=100)
             guarded("f32_4194304", quick_rate, "c4", 4194304, "f32", dev, stream, steps=50, sets=2)
             guarded("f16_4194304", quick_rate, "c5", 4194304, "f16", dev, stream, steps=50, sets=2)
+            guarded("batch_4x_c5_1048576", batch_rate, "c5", 1048576, "f16", dev, stream)
             guarded("two_streams_c5_1048576", two_stream_rate, "c5", 1048576, "f16", dev)
             guarded("two_streams_f16_4194304", two_stream_rate, "c5", 4194304, "f16", dev, steps=100, sets=2)
             guarded("plain_soa_c5_1048576", quick_rate, "c5", 1048576, "f16", dev, stream, steps=100, layout="soa")
@@ -986,6 +1076,13 @@ def main():
             guarded("closed_loop_c3_1024envs_implicit_resident", closed_loop_rate, "c3", 19456, implicit_drag=True, resident=True)
             guarded("closed_loop_c2_262144_resident", closed_loop_rate, "c2", 262144, steps=1024, resident=True)
             guarded("closed_loop_c2_1048576_resident", closed_loop_rate, "c2", 1048576, steps=512, resident=True)
+            # the compute-bound entries also get the fraction at the clock this box held under arithmetic alone
+            held = ex.get("clocks_1m", {}).get("compute_only_ghz") if isinstance(ex.get("clocks_1m"), dict) else None
+            for v in ex.values():
+                r = v.get("roofline") if isinstance(v, dict) else None
+                if held and isinstance(r, dict) and r.get("bound") == "valu-issue":
+                    r["clock_held_ghz"] = held
+                    r["frac_at_clock_held"] = r["frac"] * PEAK_CLOCK_GHZ / held
             out["extras"] = ex
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

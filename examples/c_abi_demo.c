@@ -12,6 +12,9 @@
  * of 64 fused steps from a HIP graph captured on its own stream (same bits as the eager loop).
  */
 #include <hip/hip_runtime_api.h>
+#ifdef HYDRO_DEMO_WITH_RCCL            /* add -DHYDRO_DEMO_WITH_RCCL -lrccl: the global kinetic energy from C */
+#include <rccl/rccl.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -97,6 +100,23 @@ int main(int argc, char **argv)
     CHECK_HIP(hipStreamSynchronize(stream));
     CHECK_HIP(hipMemcpy(ke, d_ke, sizeof ke, hipMemcpyDeviceToHost));
     fprintf(stderr, "kinetic energy: %.9e + %.9e J\n", ke[0], ke[1]);
+#ifdef HYDRO_DEMO_WITH_RCCL
+    /* the one collective of the path, from C: a communicator of this process's ranks (one here; one per GPU in a real
+     * job), the pair summed in place on the stream.  With one rank the sum is the value itself. */
+    {
+        ncclComm_t comm;
+        const int dev0 = 0;
+        if (ncclCommInitAll(&comm, 1, &dev0) != ncclSuccess) { fprintf(stderr, "ncclCommInitAll failed\n"); return 8; }
+        CHECK_HYDRO(h, hydro_ke_allreduce(h, comm, d_ke, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        double all[2];
+        CHECK_HIP(hipMemcpy(all, d_ke, sizeof all, hipMemcpyDeviceToHost));
+        if (all[0] != ke[0] || all[1] != ke[1]) { fprintf(stderr, "all-reduce over one rank changed the value\n"); return 8; }
+        if (hydro_ke_allreduce(h, NULL, d_ke, stream) != HYDRO_E_ARG) return 8;
+        fprintf(stderr, "global kinetic energy over %d rank(s) through RCCL: %.9e + %.9e J\n", 1, all[0], all[1]);
+        ncclCommDestroy(comm);
+    }
+#endif
 
     /* closed loop without a host round trip: 64 fused steps (wrench + integrator, ping-pong state buffers)
      * captured ONCE into a HIP graph and replayed - the step functions neither allocate nor synchronise, so

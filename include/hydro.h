@@ -40,8 +40,10 @@ extern "C" {
  * 0.3.0: dt is a double in every step / integrate entry point; the model is evaluated in fp64
  * 0.4.0: hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke (kinetic energy sampled inside the step kernel),
  *        hydro_reserve_soa; the engine holds 68 B per body and makes its plain-SoA copies on first use
- * 0.5.0: hydro_step_fused_tiled_multi (any number of closed-loop steps in one pass, the bodies stay in registers) */
-#define HYDRO_VERSION 0x000500
+ * 0.5.0: hydro_step_fused_tiled_multi (any number of closed-loop steps in one pass, the bodies stay in registers)
+ * 0.6.0: hydro_step_wrench_tiled_batch (several independent scenes in one launch); the kinetic-energy entries are one
+ *        launch (the final sum happens in the block that finishes last); hydro_ke_allreduce (RCCL from C) */
+#define HYDRO_VERSION 0x000600
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
@@ -56,6 +58,7 @@ extern "C" {
 #define HYDRO_WRENCH_FIELDS  6
 #define HYDRO_COMP_FIELDS   24
 #define HYDRO_TILE          64   /* bodies per tile of the tiled-SoA layout = one wavefront */
+#define HYDRO_BATCH_MAX     32   /* scenes per hydro_step_wrench_tiled_batch launch */
 
 typedef struct hydro_engine hydro_t;
 
@@ -155,6 +158,25 @@ int hydro_step_wrench_tiled(hydro_t *h, int64_t n, const float *state, int64_t s
                             const float *prev, int64_t prev_tile_stride, double dt,
                             float *wrench, int64_t wrench_tile_stride, void *stream);
 
+/* The same step for `count` INDEPENDENT scenes in one launch (1 <= count <= HYDRO_BATCH_MAX).  Every scene is what one
+ * hydro_step_wrench_tiled call takes - an engine (its parameters, scene scalars and, with prev == NULL, its previous
+ * velocity), n bodies, tiled state / prev / wrench buffers - and gets exactly the bits that call would give; what the
+ * batch buys is ONE ramp and drain for all of them: k replicas of a 1 M-body scene stream at the rate of a k M-body
+ * launch without the caller owning streams.  Replaces the per-prim loop of the reference at the
+ * scale of config 3's 1 024 environments (one HydrodynamicsBehavior callback per prim per step,
+ * hydrodynamics_behavior.py:131-138,176-238) when the environments live in separate buffers.
+ * One kernel instance serves the launch, so all scenes share: the device, the coefficient format (f32 / f16), the
+ * semantics, the previous-velocity mode (all prev == NULL or none), and dt.  Scene scalars (rho, g) may differ.  An
+ * engine that owns the previous velocity may appear once per launch.  Errors are reported on scenes[0].engine. */
+typedef struct hydro_scene {
+    hydro_t *engine;
+    int64_t n;
+    const float *state;  int64_t state_tile_stride;
+    const float *prev;   int64_t prev_tile_stride;     /* NULL: engine-owned previous velocity */
+    float *wrench;       int64_t wrench_tile_stride;
+} hydro_scene_t;
+int hydro_step_wrench_tiled_batch(int count, const hydro_scene_t *scenes, double dt, void *stream);
+
 /* The same step, sampling the kinetic energy on the way ("reduced in-kernel"): the kernel adds
  * 1/2 m |v|^2 (and, with `rotational`, the box-inertia term) of the bodies it already holds in registers - the state
  * it READS, i.e. the state the previous step left - reduces over the block (LDS) and the wavefront, and the block
@@ -218,6 +240,14 @@ int hydro_kinetic_energy(hydro_t *h, int64_t n, const float *const state[HYDRO_S
                          double *out_dev, void *stream);
 int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride, int rotational,
                                double *out_dev, void *stream);
+
+/* The one collective of the path: sum the pair a kinetic-energy entry left in ke_dev[0..1] over the ranks
+ * of `nccl_comm` (an ncclComm_t of RCCL; one rank per GPU), in place, on `stream` -
+ * ncclAllReduce(ke_dev, ke_dev, 2, ncclDouble, ncclSum, comm, stream).  16 bytes over xGMI: latency-bound; put it on a
+ * side stream every K steps.  RCCL is bound at the first call (the copy already loaded in the process, else librccl.so;
+ * HYDRO_RCCL_LIBRARY overrides), so a single-GPU host needs no RCCL; HYDRO_E_STATE if there is none.  New functionality
+ * named by BASELINE.json north_star; the reference has no reduction of any kind. */
+int hydro_ke_allreduce(hydro_t *h, void *nccl_comm, double *ke_dev, void *stream);
 
 /* Explicit rigid-body step standing in for PhysX in closed-loop runs:
  * semi-implicit Euler with gravity and box inertia.  state_out may alias state_in. */

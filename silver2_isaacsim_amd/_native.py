@@ -16,6 +16,16 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhydro.so")
 
 STATE_FIELDS, PREV_FIELDS, PARAM_FIELDS, WRENCH_FIELDS, COMP_FIELDS = 13, 6, 11, 6, 24
 TILE = 64
+BATCH_MAX = 32
+
+
+class Scene(ctypes.Structure):
+    """hydro_scene_t (include/hydro.h): one scene of a hydro_step_wrench_tiled_batch launch."""
+    _fields_ = [("engine", c_void_p), ("n", c_int64),
+                ("state", c_void_p), ("state_tile_stride", c_int64),
+                ("prev", c_void_p), ("prev_tile_stride", c_int64),
+                ("wrench", c_void_p), ("wrench_tile_stride", c_int64)]
+
 
 HYDRO_OK = 0
 HYDRO_SEM_NUMBA, HYDRO_SEM_WARP = 0, 1
@@ -43,6 +53,7 @@ SIGNATURES = {
     "hydro_step_wrench_ext": (c_int, [c_void_p, c_int64, _FP, _FP, c_double, _FP, c_void_p]),
     "hydro_step_wrench_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                         c_void_p, c_int64, c_void_p]),
+    "hydro_step_wrench_tiled_batch": (c_int, [c_int, POINTER(Scene), c_double, c_void_p]),
     "hydro_step_wrench_tiled_ke": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
                                            c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hydro_step_fused_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_double,
@@ -63,6 +74,7 @@ SIGNATURES = {
     "hydro_step_components_aos": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [_FP, c_void_p, c_void_p]),
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
     "hydro_kinetic_energy_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "hydro_ke_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_double, _FP, c_void_p]),
     "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "hydro_sync": (c_int, [c_void_p]),

@@ -245,12 +245,12 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     }
     // "Fully in by bounds" (:87-88): with NO keypoint above the surface the reference returns cob = position before it
     // looks at the wet points - which matters when the top keypoint is EXACTLY on the surface (z = 0 is not wet, :80):
-    // 18/24/26 points are wet then and their mean is not the centre.  Decided on the top lattice value in the
-    // association the mask was built with - it IS one of the 27 values whose sign bits were taken - so the branch and
-    // the mask cannot disagree.  (The Warp twin has no such return: its cob is the mean of the wet points whenever there
-    // are any, warp_hydrodynamics.py:59-61.)
-    const double ztop = ((pz + fabs(ex)) + fabs(ey)) + fabs(ez);
-    const uint32_t cobmask = (warp || ztop > 0.0) ? wetmask : 0u;
+    // 18/24/26 points are wet then and their mean is not the centre.  Decided on z_hi = p_z + ((|e_x| + |e_y|) + |e_z|),
+    // which is the reference's own z_max in the reference's own association (the row of R @ keypoints^T, then + p_z:
+    // numba_hydrodynamics.py:271); on exactly representable heights - the only inputs on which a tie exists - it is also
+    // the top value of the mask's lattice.  (The Warp twin has no such return: its cob is the mean of the wet points
+    // whenever there are any, warp_hydrodynamics.py:59-61.)
+    const uint32_t cobmask = (warp || zhi > 0.0) ? wetmask : 0u;
     const int cnt = __builtin_popcount(wetmask);
     const int s_i = __builtin_popcount(cobmask & lattice_mask(0, 2)) - __builtin_popcount(cobmask & lattice_mask(0, 0));
     const int s_j = __builtin_popcount(cobmask & lattice_mask(1, 2)) - __builtin_popcount(cobmask & lattice_mask(1, 0));

@@ -271,6 +271,57 @@ class HydroEngine:
             return keep[2]
         return step
 
+    @staticmethod
+    def prepare_step_wrench_tiled_batch(engines, states, dt: float, outs=None, prevs=None, ns=None, stream=None):
+        """k independent scenes in ONE launch (hydro_step_wrench_tiled_batch): engines[i] steps states[i] (tiled
+        (tiles,13,64)) into outs[i] ((tiles,6,64), allocated when None) with prevs[i] as the previous velocity (tiled
+        6-field buffers or the velocity fields of a previous state buffer; None = every engine's own).  Same bits as k
+        single calls; one ramp and drain for all of them.  Returns (step, outs): `step()` re-issues the launch on the
+        stream current at the time of the call (arguments are validated here, once)."""
+        k = len(engines)
+        if not 1 <= k <= nat.BATCH_MAX or len(states) != k:
+            raise ValueError(f"1 .. {nat.BATCH_MAX} scenes per launch, one state buffer each")
+        ns = list(ns) if ns is not None else [e.n for e in engines]
+        outs = list(outs) if outs is not None else [e.alloc_tiled(nat.WRENCH_FIELDS, n) for e, n in zip(engines, ns)]
+        arr = (nat.Scene * k)()
+        keep = []
+        for i, (e, st, n, out) in enumerate(zip(engines, states, ns, outs)):
+            e._check_tiled(st, nat.STATE_FIELDS, n)
+            e._check_tiled(out, nat.WRENCH_FIELDS, n)
+            sc = arr[i]
+            sc.engine, sc.n = e._h, n
+            sc.state, sc.state_tile_stride = st.data_ptr(), st.shape[1] * nat.TILE
+            sc.wrench, sc.wrench_tile_stride = out.data_ptr(), out.shape[1] * nat.TILE
+            if prevs is None:
+                sc.prev, sc.prev_tile_stride = None, 0
+            else:
+                pv = prevs[i]
+                if pv.shape[1] == nat.STATE_FIELDS:                 # a previous STATE buffer: its six velocity fields
+                    e._check_tiled(pv, nat.STATE_FIELDS, n)
+                    sc.prev, sc.prev_tile_stride = pv.data_ptr() + 7 * nat.TILE * 4, nat.STATE_FIELDS * nat.TILE
+                else:
+                    e._check_tiled(pv, nat.PREV_FIELDS, n)
+                    sc.prev, sc.prev_tile_stride = pv.data_ptr(), nat.PREV_FIELDS * nat.TILE
+                keep.append(pv)
+            keep += [st, out]
+        first = engines[0]
+        fn, dtc = first._lib.hydro_step_wrench_tiled_batch, ctypes.c_double(dt)
+
+        def step(stream=stream):
+            rc = fn(k, arr, dtc, first._stream(stream))
+            if rc:
+                first._check(rc)
+            return outs
+        step._keep = (keep, arr)
+        return step, outs
+
+    @staticmethod
+    def step_wrench_tiled_batch(engines, states, dt: float, outs=None, prevs=None, ns=None, stream=None):
+        """One launch for k scenes; returns the list of wrench buffers.  See prepare_step_wrench_tiled_batch."""
+        step, outs = HydroEngine.prepare_step_wrench_tiled_batch(engines, states, dt, outs, prevs, ns, stream)
+        step()
+        return outs
+
     def step_fused_tiled(self, state: torch.Tensor, prev_state: torch.Tensor, n: int, dt: float,
                          state_out: torch.Tensor | None = None, wrench: torch.Tensor | None = None,
                          implicit_drag: bool = False, stream=None, ke_out: torch.Tensor | None = None,
@@ -456,6 +507,14 @@ class HydroEngine:
         self._check(self._lib.hydro_kinetic_energy(self._h, state.shape[1], self._table(state, nat.STATE_FIELDS),
                                                    int(bool(rotational)), out.data_ptr(), self._stream(stream)))
         return out
+
+    def ke_allreduce(self, nccl_comm: int, ke: torch.Tensor, stream=None) -> torch.Tensor:
+        """Sum the pair a kinetic-energy entry left in `ke` over the ranks of an RCCL communicator (raw ncclComm_t
+        address), in place, on `stream` (hydro_ke_allreduce: the C-level route; the Python monitor of simulate.py uses
+        torch.distributed for the same collective)."""
+        self._check_ke_out(ke)
+        self._check(self._lib.hydro_ke_allreduce(self._h, ctypes.c_void_p(nccl_comm), ke.data_ptr(), self._stream(stream)))
+        return ke
 
     def integrate(self, state_in: torch.Tensor, wrench: torch.Tensor, dt: float,
                   state_out: torch.Tensor | None = None, stream=None) -> torch.Tensor:

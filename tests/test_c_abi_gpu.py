@@ -17,9 +17,9 @@ def test_plain_c_host_program(tmp_path, native_built):
     exe = str(tmp_path / "c_abi_demo")
     lib_dir = os.path.join(REPO, "silver2_isaacsim_amd", "lib")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cmd = ["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(REPO, "examples", "c_abi_demo.c"),
+    cmd = ["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", "-DHYDRO_DEMO_WITH_RCCL", os.path.join(REPO, "examples", "c_abi_demo.c"),
            "-I", os.path.join(rocm, "include"), "-I", os.path.join(REPO, "include"),
-           "-L", lib_dir, "-lhydro", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+           "-L", lib_dir, "-lhydro", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
            f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", "-o", exe]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -42,6 +42,7 @@ def test_plain_c_host_program(tmp_path, native_built):
     assert err.max() <= 1e-5
     assert "bit-identical to the eager loop" in run.stderr                         # 64 fused steps from a HIP graph, from C
     assert "resident loop: 63 + 1 steps in two launches, bit-identical" in run.stderr  # hydro_step_fused_tiled_multi from C
+    assert "global kinetic energy over 1 rank(s) through RCCL" in run.stderr          # hydro_ke_allreduce: SURVEY.md 8e, from C
     ke_line = [l for l in run.stderr.splitlines() if l.startswith("kinetic energy")][0]
     lin = float(ke_line.split()[2])
     assert lin == pytest.approx(ho.kinetic_energy(fx["state"][:n], fx["params"][:n])[0], rel=1e-8)

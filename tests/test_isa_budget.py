@@ -79,3 +79,14 @@ def test_array_of_structs_kernel_keeps_nt_stores_and_row_accesses(assembly):
     assert sum("global_store_dwordx3" in l for l in stores) == 2 and all(l.rstrip().endswith(" nt") for l in stores)
     loads = [l for l in body.splitlines() if re.match(r"\s+global_load_", l)]
     assert any("global_load_dwordx3" in l for l in loads) and any("global_load_dwordx4" in l for l in loads)
+
+
+def test_committed_instruction_mix_is_current(assembly):
+    """profiles/isa_mix.json (scripts/isa_mix.py) is what bench.py prices the compute-bound kernels with (the VALU-issue
+    roofline of the resident closed loop): it must describe the code that is built."""
+    import json
+    from scripts import isa_mix
+    committed = json.load(open(os.path.join(REPO, "profiles", "isa_mix.json")))["kernels"]
+    assert committed == isa_mix.mix(assembly), "run `python scripts/isa_mix.py` and commit profiles/isa_mix.json"
+    loop = next(v for k, v in committed.items() if k.startswith("resident closed loop, one step ("))
+    assert loop["valu_total"] <= 530                          # the per-step loop of the resident kernel (round 3: 527 + 3)

@@ -144,6 +144,26 @@ def test_surface_ties_fixture_host(emul):
     assert top_tie.sum() > 400 and np.array_equal(comps[top_tie, 6, :], fx["state"][top_tie, 0:3])      # cob = position, exactly
 
 
+def test_quantised_fuzz_host(emul):
+    """200 000 quantised bodies (tests/populations.py surface_ties, another seed: cube rotations with the fp32 sqrt(1/2),
+    thirds of a turn, non-unit quaternions; p_z on ties or on the 1/8 grid; box dimensions 1/4 .. 2): every comparison of
+    the model falls on exact numbers somewhere in this population.  Net wrench within the gate, calculator surface
+    (eight vectors, centres to half an fp32 ulp) against the oracle."""
+    import populations
+    st, pv, pr, kind = populations.surface_ties(n=200000, seed=2026)
+    census = populations.tie_census(st, pr)
+    assert census["top on the surface, not all keypoints on it"] > 20000 and census["a face centre on the surface"] > 50000
+    f, t, r = emul(st, pv, pr, populations.RHO, populations.G, populations.DT)
+    rf, rt, aux = ho.step_wrench(st, pv, pr, populations.RHO, populations.G, populations.DT)
+    err = ho.wrench_error(f, t, rf, rt, pr, populations.RHO, populations.G)
+    assert err.max() <= GATE, f"{(err > GATE).sum()} bodies above the gate, max {err.max():.3e}"
+    assert np.abs(r - aux["ratio"]).max() < 5e-7
+    acc32 = ((st[:, 7:13].astype(np.float64) - pv.astype(np.float64)) / populations.DT).astype(np.float32)
+    comps, cr = emul.components(st, acc32, pr, populations.RHO, populations.G)
+    ref = ho.solve_components(st, acc32.astype(np.float64), pr.astype(np.float64), populations.RHO, populations.G)
+    check_components(comps, cr, ref)
+
+
 def check_components(comps, ratio, ref):
     """comps (n,8,3) fp32 / ratio (n) against the oracle's dict: forces and torques to 1e-6 of the body's largest term,
     centres to half an fp32 ulp, exact zeros for dry bodies."""

@@ -662,6 +662,73 @@ def test_tiled_entry_same_bits_as_plain_soa(name, n, native_built):
     eng.close()
 
 
+@pytest.mark.parametrize("coeff", ["f32", "f16"])
+@pytest.mark.parametrize("own_prev", [False, True])
+def test_batched_scenes_in_one_launch_give_the_bits_of_single_launches(coeff, own_prev, native_built):
+    """hydro_step_wrench_tiled_batch: k independent scenes, one launch.  Ragged sizes (1, 63, 257, 4096, 100 003 bodies:
+    scenes that end inside a tile and inside a block), different scene scalars per scene, caller-owned or engine-owned
+    previous velocity: every scene's wrench (and, engine-owned, its stored previous velocity) has the bits of its own
+    hydro_step_wrench_tiled call."""
+    sizes = [4096, 1, 257, 100003, 63, 1000]
+    engines, states, prevs, refs, host_prev = [], [], [], [], []
+    for k, n in enumerate(sizes):
+        sc = scenes.scene_c4(n=n, seed=100 + k)
+        eng = HydroEngine(n, DEV, 1000.0 + 5.0 * k, 9.81 - 0.01 * k)               # scene scalars differ
+        eng.set_params(sc.params, coeff)
+        st, pv = tiled(sc.state), tiled(sc.prev)
+        if own_prev:
+            eng.set_prev_velocity(sc.prev)
+            refs.append(eng.step_wrench_tiled(st, n, sc.dt).clone())
+            eng.set_prev_velocity(sc.prev)
+        else:
+            refs.append(eng.step_wrench_tiled(st, n, sc.dt, prev=pv).clone())
+        engines.append(eng); states.append(st); prevs.append(pv); host_prev.append(sc.state[:, 7:13])
+    dt = scenes.scene_c4(n=1).dt
+    outs = HydroEngine.step_wrench_tiled_batch(engines, states, dt, prevs=None if own_prev else prevs)
+    torch.cuda.synchronize()
+    for k, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o, r), f"scene {k} ({sizes[k]} bodies)"
+        if own_prev:
+            assert np.array_equal(engines[k].get_prev_velocity().cpu().numpy().T, host_prev[k])
+    # prepared form: re-issued, follows the buffers' contents; the previous STATE buffer's velocity fields serve as prev
+    if not own_prev:
+        prev_states = []
+        for k, n in enumerate(sizes):
+            ps = torch.zeros((HydroEngine.tiles(n), 13, 64), device=DEV); ps[:, 7:13, :] = prevs[k]
+            prev_states.append(ps)
+        step, outs2 = HydroEngine.prepare_step_wrench_tiled_batch(engines, states, dt, prevs=prev_states)
+        step(); torch.cuda.synchronize()
+        assert all(torch.equal(o, r) for o, r in zip(outs2, refs))
+        states[3][:, 2, :] -= 0.125
+        step(); torch.cuda.synchronize()
+        assert torch.equal(outs2[3], engines[3].step_wrench_tiled(states[3], sizes[3], dt, prev=prevs[3])) and not torch.equal(outs2[3], refs[3])
+    for e in engines:
+        e.close()
+
+
+def test_batched_launch_refuses_what_one_kernel_instance_cannot_serve(native_built):
+    fx = load_golden("c2")
+    n, dt = 512, float(fx["dt"])
+    def make(coeff="f32", sem="numba"):
+        e = HydroEngine(n, DEV); e.set_params(fx["params"][:n], coeff); e.set_semantics(sem); return e
+    a, b = make(), make()
+    st, pv = tiled(fx["state"][:n]), tiled(fx["prev"][:n])
+    HydroEngine.step_wrench_tiled_batch([a, b], [st, st], dt, prevs=[pv, pv])            # fine
+    with pytest.raises(HydroError, match="share"):                                         # f32 and f16 records in one launch
+        c = make("f16"); HydroEngine.step_wrench_tiled_batch([a, c], [st, st], dt, prevs=[pv, pv])
+    with pytest.raises(HydroError, match="once per launch"):                               # engine-owned prev, same engine twice
+        HydroEngine.step_wrench_tiled_batch([a, a], [st, st], dt)
+    with pytest.raises(ValueError):
+        HydroEngine.step_wrench_tiled_batch([a] * 33, [st] * 33, dt, prevs=[pv] * 33)
+    with pytest.raises(HydroError, match="HYDRO_E_ARG"):
+        HydroEngine.step_wrench_tiled_batch([a, b], [st, st], 0.0, prevs=[pv, pv])
+    empty = HydroEngine(n, DEV)                                                             # no parameters set
+    with pytest.raises(HydroError, match="HYDRO_E_STATE"):
+        HydroEngine.step_wrench_tiled_batch([a, empty], [st, st], dt, prevs=[pv, pv])
+    for e in (a, b, c, empty):
+        e.close()
+
+
 def test_tiled_previous_velocity_modes(native_built):
     fx = load_golden("c4")
     rho, g, dt = float(fx["rho"]), float(fx["g"]), float(fx["dt"])

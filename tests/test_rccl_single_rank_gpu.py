@@ -76,3 +76,47 @@ def test_bench_strong_leg_over_rccl(native_built):
     assert cs["bodies_this_rank"] == 262144 and cs["kinetic_energy"]["samples"] == 2 and cs["kinetic_energy"]["host_waits"] == 0
     assert d["collectives"] == "nccl (RCCL), 1 rank(s)"
     assert d["barrier"] == "node-local shared-memory epoch barrier"      # built over the RCCL group's own collectives
+
+
+CHILD_C_ROUTE = r'''
+import ctypes, os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.environ["HYDRO_REPO"])
+from silver2_isaacsim_amd import scenes
+from silver2_isaacsim_amd.engine import HydroEngine
+torch.cuda.set_device(0)
+sc = scenes.scene_c4(n=70000, seed=3)
+eng = HydroEngine(sc.n, "cuda:0", sc.rho, sc.g)
+eng.set_params(sc.params)
+st = torch.from_numpy(scenes.to_tiled(sc.state)).to("cuda:0")
+ke = eng.kinetic_energy(st, rotational=True)
+local = ke.clone()
+rccl = ctypes.CDLL(os.environ.get("HYDRO_TEST_RCCL", "librccl.so.1"))       # whichever copy the process resolves: the library binds the same one
+comm = ctypes.c_void_p()
+dev0 = (ctypes.c_int * 1)(0)
+assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, dev0) == 0
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+eng.ke_allreduce(comm.value, ke, stream=side)                                # 16 bytes, on a side stream
+side.synchronize()
+ok = torch.equal(ke, local)
+try:
+    eng.ke_allreduce(0, ke)
+    refused = False
+except Exception as e:
+    refused = "HYDRO_E_ARG" in str(e)
+rccl.ncclCommDestroy(comm)
+print(json.dumps({"same": bool(ok), "refused_null": refused, "ke": ke.tolist()}))
+eng.close()
+'''
+
+
+def test_ke_allreduce_from_the_c_abi(native_built):
+    """hydro_ke_allreduce (SURVEY.md 8e: ncclAllReduce(count 2, ncclDouble, ncclSum) on a side stream) with a one-rank
+    communicator made through RCCL's own C API - no torch.distributed anywhere: the route a plain-C host takes."""
+    import json
+    env = dict(os.environ, HYDRO_REPO=REPO)
+    res = subprocess.run([sys.executable, "-c", CHILD_C_ROUTE], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["same"] and d["refused_null"] and d["ke"][0] > 0
