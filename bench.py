@@ -691,6 +691,7 @@ def clock_probes_leg(n: int, dev, stream):
     c = probes.clock_probes(n, dev, stream, seconds=1.0)
     return {"n": n, "whole_body_ghz": c["whole_body"]["ghz"], "memory_only_ghz": c["memory_only"]["ghz"],
             "compute_only_ghz": c["compute_only"]["ghz"],
+            "sustained_arithmetic_ghz": c["sustained_arithmetic"]["ghz"],     # 64 passes of the body per wave: the resident loop's load
             "wave_lifetime_us": {k: v["wave_lifetime_us"] for k, v in c.items()},
             "how": "in-kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the waves of 50 launches"}
 
@@ -886,7 +887,7 @@ def main():
     # HYDRO_BENCH_FORCE_GROUP=1 (with HYDRO_DIST_ALWAYS=1): WORLD_SIZE=1 still builds a one-rank process group and takes
     # the N > 1 code path - how a single-GPU box runs the real RCCL calls (tests/test_rccl_single_rank_gpu.py)
     force_group = os.environ.get("HYDRO_BENCH_FORCE_GROUP") == "1"
-    hd.init_process_group(force=force_group)
+    hd.init_process_group(force=force_group, node_barrier=True)       # (a measurement: its ranks may spin on a core for the microseconds a timed region opens in)
     multi = world > 1 or force_group
     # one rank per GPU; HYDRO_BENCH_SHARE_GPU=1 (with HYDRO_DIST_BACKEND=gloo) lets several ranks share
     # GPU 0 to rehearse the multi-rank path on a single-GPU box
@@ -1076,8 +1077,8 @@ def main():
             guarded("closed_loop_c3_1024envs_implicit_resident", closed_loop_rate, "c3", 19456, implicit_drag=True, resident=True)
             guarded("closed_loop_c2_262144_resident", closed_loop_rate, "c2", 262144, steps=1024, resident=True)
             guarded("closed_loop_c2_1048576_resident", closed_loop_rate, "c2", 1048576, steps=512, resident=True)
-            # the compute-bound entries also get the fraction at the clock this box held under arithmetic alone
-            held = ex.get("clocks_1m", {}).get("compute_only_ghz") if isinstance(ex.get("clocks_1m"), dict) else None
+            # the compute-bound entries also get the fraction at the clock this box held under SUSTAINED arithmetic (64 passes per wave)
+            held = ex.get("clocks_1m", {}).get("sustained_arithmetic_ghz") if isinstance(ex.get("clocks_1m"), dict) else None
             for v in ex.values():
                 r = v.get("roofline") if isinstance(v, dict) else None
                 if held and isinstance(r, dict) and r.get("bound") == "valu-issue":

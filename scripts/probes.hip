@@ -155,7 +155,9 @@ __global__ void __launch_bounds__(256) probe_compute(const PArgs a, double rho, 
 // in a buffer nothing else reads; clock = d(memtime) / d(memrealtime) x 100 MHz, median over the waves of a launch.
 //   KIND 0: the product kernel's whole body (28 loads from ITS tile, solve_wrench, 6 stores) - what the tiled wrench
 //           kernel does, stamped;   KIND 1: memory only (loads, trivial combine, 6 stores);   KIND 2: compute only
-//           (L2-resident inputs, one store).
+//           (L2-resident inputs, one store);   KIND 3: SUSTAINED arithmetic - the body 64 times over in registers (each
+//           pass fed by the last one's wrench), the load the resident closed loop (hydro_step_fused_tiled_multi) puts
+//           on the chip: long fp64 runs draw more power than one pass between loads, and the clock follows.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ void __launch_bounds__(256) probe_clock(const PArgs a, uint64_t* __restrict__ stamps, double rho, double g, double inv_dt)
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(256) probe_clock(const PArgs a, uint64_t* __re
     const uint32_t i = blockIdx.x * 256 + threadIdx.x, tile = i >> 6, lane = i & 63u;
     if (tile >= a.tiles) return;
     const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    const uint32_t lt = KIND == 2 ? (tile & 63u) : tile;
+    const uint32_t lt = KIND >= 2 ? (tile & 63u) : tile;
     const float* s = a.st + (size_t)lt * 832 + lane; const float* p = a.pv + (size_t)lt * 384 + lane;
     const float* q = a.prm + (size_t)lt * 480 + lane;
     const unsigned short* hq = reinterpret_cast<const unsigned short*>(a.prm + (size_t)lt * 480 + 256) + lane;
@@ -192,7 +194,16 @@ __global__ void __launch_bounds__(256) probe_clock(const PArgs a, uint64_t* __re
         b.dimx = ldnt(q); b.dimy = ldnt(q + 64); b.dimz = ldnt(q + 128); mass = ldnt(q + 192);
         b.cd_lin = h2f(ldnt(hq)); b.cd_ang = h2f(ldnt(hq + 64)); b.damp_lin = h2f(ldnt(hq + 128)); b.damp_ang = h2f(ldnt(hq + 192));
         b.lift = h2f(ldnt(hq + 256)); b.am_lin = h2f(ldnt(hq + 320)); b.am_ang = h2f(ldnt(hq + 384));
-        const hydro::Wrench w = hydro::solve_wrench(b, pv, mass, rho, g, inv_dt, false);
+        hydro::Wrench w = hydro::solve_wrench(b, pv, mass, rho, g, inv_dt, false);
+        if constexpr (KIND == 3) {
+#pragma unroll 1
+            for (int it = 1; it < 64; ++it) {
+                pv[0] = b.vx; pv[1] = b.vy; pv[2] = b.vz; pv[3] = b.wx; pv[4] = b.wy; pv[5] = b.wz;
+                b.vx += 1e-7f * w.fx; b.vy += 1e-7f * w.fy; b.vz += 1e-7f * w.fz;
+                b.wx += 1e-7f * w.tx; b.wy += 1e-7f * w.ty; b.wz += 1e-7f * w.tz; b.pz += 1e-3f * b.vz;
+                w = hydro::solve_wrench(b, pv, mass, rho, g, inv_dt, false);
+            }
+        }
         if constexpr (KIND == 0) {
             stnt(o, w.fx); stnt(o + 64, w.fy); stnt(o + 128, w.fz); stnt(o + 192, w.tx); stnt(o + 256, w.ty); stnt(o + 320, w.tz);
         } else {
@@ -213,6 +224,7 @@ extern "C" int probe_launch_clock(int kind, const PArgs* a, void* stamps, void* 
         case 0: hipLaunchKernelGGL(probe_clock<0>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
         case 1: hipLaunchKernelGGL(probe_clock<1>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
         case 2: hipLaunchKernelGGL(probe_clock<2>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
+        case 3: hipLaunchKernelGGL(probe_clock<3>, grid, blk, 0, s, *a, st, 1025.0, 9.81, 60.0); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -314,5 +326,30 @@ extern "C" int probe_launch(int which, const PArgs* a, const void* src, void* ds
         case 7: hipLaunchKernelGGL(probe_dword_wt, grid, blk, 0, s, *a); break;
         default: return -1;
     }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fp64 reciprocal / square-root forms of hydro_body.h (fp32 hardware seed + one Newton step) as the DEVICE computes
+// them, for tests/test_numerics_gpu.py: the CPU instantiation of that header uses libm instead, so the seeds' behaviour at
+// and beyond the limits the header documents (x = 0, x < 1e-36, x beyond the fp32 range) can only be seen here.
+// out[4 i + 0..3] = rcp64(x_i), sqrt64(x_i), rsqrt64(x_i), x_i * rsqrt64(x_i)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void probe_seeds(const double* __restrict__ x, double* __restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    out[4 * i] = hydro::rcp64(v);
+    out[4 * i + 1] = hydro::sqrt64(v);
+    const double r = hydro::rsqrt64(v);
+    out[4 * i + 2] = r;
+    out[4 * i + 3] = v * r;
+}
+
+extern "C" int probe_launch_seeds(const void* x, void* out, uint32_t n, void* stream)
+{
+    hipLaunchKernelGGL(probe_seeds, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const double*>(x), static_cast<double*>(out), n);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -159,7 +159,7 @@ def clock_probes(n: int, dev, stream, seconds: float = 2.0) -> dict:
     s_memrealtime around its body.  Each kind is run back to back for `seconds` first (the clock needs that long to
     settle), then 50 stamped launches are evaluated: median over waves and launches of cycles / real time.
     Returns {kind: {"ghz", "wave_lifetime_us", "us_per_launch"}} for the whole body (what the tiled wrench kernel does),
-    memory only, compute only."""
+    memory only, compute only, and sustained arithmetic (64 passes of the body per wave: the resident closed loop's load)."""
     import time
     import bench
     L = lib()
@@ -178,7 +178,7 @@ def clock_probes(n: int, dev, stream, seconds: float = 2.0) -> dict:
     sp = ctypes.c_void_p(stream.cuda_stream)
     out = {}
     with torch.cuda.stream(stream):
-        for kind, name in ((0, "whole_body"), (1, "memory_only"), (2, "compute_only")):
+        for kind, name in ((0, "whole_body"), (1, "memory_only"), (2, "compute_only"), (3, "sustained_arithmetic")):
             t0 = time.perf_counter(); r = 0
             while time.perf_counter() - t0 < seconds:
                 for _ in range(64):

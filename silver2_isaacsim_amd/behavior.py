@@ -499,9 +499,14 @@ class KitHost:
     """Binds the `SimHost` protocol to Omniverse Kit / Isaac Sim.  Imports are lazy so
     that this module loads without `omni`, `pxr`, `carb` (none exist outside Kit)."""
 
-    def __init__(self, device: str = "cuda:0", config_dir: str | None = None):
+    def __init__(self, device: str = "cuda:0", config_dir: str | None = None, use_builtin_table: bool = False):
+        """config_dir: where hydrodynamics_config.json is looked for - the directory of the SCRIPTED behaviour file in
+        the reference (hydrodynamics_behavior.py:76-77); pass that directory (default: this package's).
+        use_builtin_table: with no JSON there, apply the table the reference ships (config.default_config()) instead
+        of the reference's rule, which is to warn and keep the USD values (:79-81)."""
         self.device = device
         self._config_dir = config_dir or os.path.dirname(os.path.abspath(__file__))
+        self._use_builtin_table = bool(use_builtin_table)
         self._sim_context = None
 
     def ensure_simulation_context(self):
@@ -567,7 +572,10 @@ class KitHost:
         return omni.physx.get_physx_interface().subscribe_physics_step_events(callback)
 
     def config_path(self):
-        # a hydrodynamics_config.json beside the script wins (as in the reference, :76-77);
-        # without one the built-in table - the values the reference ships - is used
+        # The reference's rule (:76-81): the JSON beside the script is applied; if there is none, a warning, and the
+        # USD attribute values stay as they are (cfg.load_config does exactly that for a path that does not exist).
+        # Only a host that ASKED for it (use_builtin_table=True) gets the shipped table in that case (path None).
         p = os.path.join(self._config_dir, cfg.CONFIG_FILE_NAME)
-        return p if os.path.exists(p) else None
+        if self._use_builtin_table and not os.path.exists(p):
+            return None
+        return p

@@ -32,10 +32,14 @@ def env_rank_world() -> tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend: str | None = None, device_id: int | None = None, force: bool = False) -> bool:
+def init_process_group(backend: str | None = None, device_id: int | None = None, force: bool = False,
+                       node_barrier: bool = False) -> bool:
     """Initialise torch.distributed from the env when WORLD_SIZE>1 (or, with force=True, a one-rank group: the way a
     single-GPU box drives the real RCCL calls).  Returns True if a group is active.  backend None -> 'nccl' (= RCCL)
-    on GPU, 'gloo' otherwise."""
+    on GPU, 'gloo' otherwise.
+    node_barrier=True: barrier() of this module becomes the node-local shared-memory barrier (NodeBarrier) - a
+    measurement tool: its ranks spin on a host core for the microseconds a timed region opens and closes in.  bench.py
+    asks for it; a host that also runs a simulator does not, and gets torch.distributed's own barrier."""
     rank, local_rank, world = env_rank_world()
     if world <= 1 and not force:
         return False
@@ -52,9 +56,10 @@ def init_process_group(backend: str | None = None, device_id: int | None = None,
         kw["device_id"] = torch.device("cuda", dev)
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     global _node_barrier
-    _node_barrier = False           # (a new group: a barrier of an earlier one is not its barrier)
-    _setup_node_barrier()           # here, not at the first barrier(): its set-up takes milliseconds of host time, and a
-    return True                     # GPU left idle that long right before a timed region starts it at a lower clock
+    _node_barrier = None            # (a new group: a barrier of an earlier one is not its barrier)
+    if node_barrier:                # here, not at the first barrier(): its set-up takes milliseconds of host time, and a
+        enable_node_barrier()       # GPU left idle that long right before a timed region starts it at a lower clock
+    return True
 
 
 def collective_device(default: torch.device | str) -> torch.device:
@@ -125,19 +130,25 @@ class NodeBarrier:
         dist.all_gather_object(ids, (socket.gethostname(), boot))
         if len(set(ids)) != 1 or not os.path.isdir("/dev/shm"):
             return None
-        path = f"/dev/shm/hydro_barrier_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
+        # /dev/shm is world-writable: the name is unpredictable (rank 0 draws it, the others are told), the file must not
+        # exist yet (O_EXCL) and no component may be a symbolic link somebody planted (O_NOFOLLOW)
+        name = [f"/dev/shm/hydro_barrier_{os.getuid()}_{os.urandom(12).hex()}" if rank == 0 else None]
+        dist.broadcast_object_list(name, src=0)
+        path = name[0]
         size = max(4096, world * cls.LINE * 8)
         fd, mm, ok = -1, None, True
         try:
             if rank == 0:
-                fd = os.open(path, os.O_CREAT | os.O_TRUNC | os.O_RDWR, 0o600)
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW | os.O_RDWR, 0o600)
                 os.ftruncate(fd, size)                    # zero-filled
         except OSError:
             ok = False
         dist.barrier()                                    # the file exists with its final size
         try:
             if rank != 0:
-                fd = os.open(path, os.O_RDWR)
+                fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
+                if os.fstat(fd).st_uid != os.getuid():
+                    raise OSError("barrier page owned by another user")
             mm = mmap.mmap(fd, size)
             os.close(fd)
         except (OSError, ValueError):
@@ -166,7 +177,15 @@ class NodeBarrier:
         t_end = None
         while int(col.min()) < e:
             spins += 1
-            if spins & 0xFFFF == 0:                       # a rank that died must not hang the others for ever
+            # ranks of a timed region arrive within microseconds of each other: spin for those; a rank that is late by
+            # more (it is still setting up, or the host is oversubscribed) is waited for politely - give the core away,
+            # then sleep - so that the barrier never burns a core the late rank, or a simulator, needs
+            if spins > 2000:
+                if spins > 20000:
+                    time.sleep(50e-6)
+                else:
+                    os.sched_yield()
+            if spins & 0xFFF == 0:                        # a rank that died must not hang the others for ever
                 now = time.monotonic()
                 if t_end is None:
                     t_end = now + timeout_s
@@ -174,22 +193,26 @@ class NodeBarrier:
                     raise TimeoutError(f"node barrier: rank {self.rank} waited {timeout_s:.0f} s at epoch {e}: {col.tolist()}")
 
 
-_node_barrier: "NodeBarrier | None | bool" = False          # False = not tried yet
+_node_barrier: "NodeBarrier | None" = None                  # None = torch.distributed's own barrier
 
 
-def _setup_node_barrier() -> None:
+def enable_node_barrier() -> bool:
+    """COLLECTIVE (every rank of the group calls it at the same point): switch barrier() to the node-local shared-memory
+    barrier.  False - and barrier() stays torch.distributed's - when the ranks span hosts, /dev/shm is unusable, or
+    HYDRO_BARRIER=dist is set."""
     global _node_barrier
-    if _node_barrier is False and dist.is_available() and dist.is_initialized():
-        _node_barrier = None if os.environ.get("HYDRO_BARRIER") == "dist" else NodeBarrier.create()
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("HYDRO_BARRIER") == "dist":
+        return False
+    if _node_barrier is None:
+        _node_barrier = NodeBarrier.create()
+    return _node_barrier is not None
 
 
 def barrier():
-    """Barrier over all ranks; no-op without a process group.  Ranks on one host use NodeBarrier (set up collectively by
-    init_process_group, or at the first call when the group was made elsewhere); HYDRO_BARRIER=dist, or ranks on several
-    hosts, fall back to torch.distributed's own."""
+    """Barrier over all ranks; no-op without a process group.  torch.distributed's own unless a measurement asked for the
+    node-local one (init_process_group(node_barrier=True) / enable_node_barrier())."""
     if not _collectives_on():
         return
-    _setup_node_barrier()
     if _node_barrier is None:
         dist.barrier()
     else:
@@ -199,6 +222,4 @@ def barrier():
 def barrier_kind() -> str:
     if not _collectives_on():
         return "none (single process)"
-    if _node_barrier is False:
-        return "not used yet"
     return "torch.distributed.barrier" if _node_barrier is None else "node-local shared-memory epoch barrier"

@@ -117,3 +117,25 @@ def test_scene_shard_is_a_view_of_the_block():
     parts = [sc.shard(r, 4) for r in range(4)]
     assert np.array_equal(np.concatenate([p.state for p in parts]), sc.state)
     assert parts[2].info["shard"][:2] == (2, 4)
+
+
+def test_kit_host_follows_the_reference_rule_for_a_missing_json(tmp_path, caplog):
+    """hydrodynamics_behavior.py:76-81: the JSON beside the script is applied; without one, a warning and the USD values
+    stay.  KitHost hands load_config the path either way (the shipped table only when use_builtin_table=True)."""
+    import json
+    import logging
+    from silver2_isaacsim_amd import config as cfg
+    from silver2_isaacsim_amd.behavior import KitHost
+    empty = tmp_path / "no_json_here"; empty.mkdir()
+    host = KitHost(config_dir=str(empty))
+    p = host.config_path()
+    assert p == str(empty / cfg.CONFIG_FILE_NAME)
+    with caplog.at_level(logging.WARNING):
+        assert cfg.load_config(p) is None                     # -> _apply_json_config returns: USD values untouched
+    assert "Config missing" in caplog.text
+    assert KitHost(config_dir=str(empty), use_builtin_table=True).config_path() is None       # load_config(None) = the shipped table
+    assert cfg.load_config(None) == cfg.default_config()
+    edited = dict(cfg.default_config()); edited["globals"] = {"waterDensity": 999.0, "gravity": 9.8}
+    (empty / cfg.CONFIG_FILE_NAME).write_text(json.dumps(edited))
+    for h in (KitHost(config_dir=str(empty)), KitHost(config_dir=str(empty), use_builtin_table=True)):
+        assert cfg.load_config(h.config_path())["globals"]["waterDensity"] == 999.0      # a user's JSON always wins
