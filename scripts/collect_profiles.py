@@ -141,6 +141,29 @@ if os.path.isdir(os.path.join(src, "aos_fetch")):
                   f"--pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 (gfx950; the x2 calibration is that of the 4-byte streaming pattern; "
                   f"2 x FETCH vs the known read bytes here: {100.0 * (2.0 * fa / (na * 120) - 1.0):+.2f}%); profiles/{tag}_aos_1m_kernel_stats.csv, {tag}_aos_4m_kernel_stats.csv",
     }
+# auxiliary kernels (round 4): kinetic energy in one launch, the resident closed loop (SQ counters), several scenes per launch
+if os.path.isdir(os.path.join(src, "ke1m")):
+    for sub, name in (("ke1m", "ke_1m"), ("ke4m", "ke_4m"), ("resident", "resident_1m"), ("batch", "batch_4x1m")):
+        shutil.copy(one(f"{sub}/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+    aux = {k: json.load(open(os.path.join(src, f"aux_{k}.json"))) for k in ("ke1m", "ke4m", "resident", "batch")}
+    rows = []
+    with open(one("resident_sq/**/*counter_collection.csv"), newline="") as f:
+        for r in csv.DictReader(f):
+            if "step_fused_multi_tiled_kernel" in r["Kernel_Name"]:
+                rows.append((int(r["Dispatch_Id"]), r["Counter_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    with open(os.path.join(dst, f"{tag}_resident_pmc_SQ.csv"), "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["dispatch_id", "kernel", "counter", "value"])
+        for d_, c_, v_ in rows:
+            w.writerow([d_, "step_fused_multi_tiled_kernel (64 steps per launch, 1 048 576 bodies)", c_, f"{v_:.6f}"])
+    sqr = {}
+    for _, c_, v_ in rows:
+        sqr.setdefault(c_, []).append(v_)
+    aux["resident"]["sq_per_launch_median"] = {k: statistics.median(v) for k, v in sorted(sqr.items())}
+    if "SQ_INSTS_VALU" in sqr and "SQ_WAVES" in sqr:
+        aux["resident"]["valu_instructions_per_wave_per_step_from_counters"] = statistics.median(sqr["SQ_INSTS_VALU"]) / statistics.median(sqr["SQ_WAVES"]) / 64.0
+    json.dump(aux, open(os.path.join(dst, f"{tag}_aux_kernels.json"), "w"), indent=1)
+    print(json.dumps(aux, indent=1)[:3000])
 json.dump(tr, open(path, "w"), indent=1)
 print(json.dumps(tr.get("c5-f32:aos"), indent=1))
 print(json.dumps(tr["c5:tiled"], indent=1))

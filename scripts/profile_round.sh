@@ -25,6 +25,14 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write4m" 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/allkernels" -- python3 bench.py --cpu-seconds 0 --no-live-traffic > "$out/bench_allkernels.json" 2> "$out/allkernels.err" || exit 1
 find "$out/allkernels" -name "*kernel_trace.csv" -delete
 bash scripts/profile_aos.sh "$tag" || exit 1
+# auxiliary kernels (round 4): the stand-alone kinetic energy (one launch), the resident closed loop (VALU-bound: SQ counters),
+# several scenes in one launch
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/ke1m" -- python3 scripts/run_aux.py ke 1048576 2000 > "$out/aux_ke1m.json" 2> "$out/ke1m.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/ke4m" -- python3 scripts/run_aux.py ke 4194304 1000 > "$out/aux_ke4m.json" 2> "$out/ke4m.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/resident" -- python3 scripts/run_aux.py resident 1048576 40 > "$out/aux_resident.json" 2> "$out/resident.err" || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/resident_sq" -- python3 scripts/run_aux.py resident 1048576 8 > "$out/aux_resident_sq.json" 2> "$out/resident_sq.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/batch" -- python3 scripts/run_aux.py batch 1048576 400 > "$out/aux_batch.json" 2> "$out/batch.err" || exit 1
+find "$out/ke1m" "$out/ke4m" "$out/resident" "$out/batch" -name "*kernel_trace.csv" -delete
 find "$out/stats4m" -name "*kernel_trace.csv" -size +20M -delete
 # keep the merge-back small: the per-dispatch traces of the stats run are large
 find "$out/stats" -name "*kernel_trace.csv" -size +20M -delete

@@ -68,6 +68,9 @@ constexpr double kClampEps = 1e-6;      // hydrodynamics_behavior.py:224
 // so even a 1e5-fold cancellation downstream stays at 1e-9.  5 and 7 instructions where the IEEE-exact sequences the
 // compiler expands `/` and sqrt() to take ~15 and ~25.  Arguments are within fp32 range wherever the result is used
 // (guarded by the model's own 1e-6 thresholds).  Plain libm on the host instantiation.
+// Limits, pinned on the device by tests/test_numerics_gpu.py: rcp64 is good for 1.2e-38 < x < 8.5e37 (x and 1/x normal
+// fp32 numbers; beyond that the seed flushes to 0 and so does the result; rcp64(0) is not a number - its callers guard
+// the zero); sqrt64 / rsqrt64 for 1e-36 <= x <= 3.4e38 (below: the seed of 1e-36, sqrt64(0) = 0 exactly; above: 0).
 HYDRO_FN double rcp64(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
