@@ -97,12 +97,28 @@ ACCEL = (STATE[:, 7:13].astype(np.float64) - PREV.astype(np.float64)) / DT      
 ACCEL32 = ACCEL.astype(np.float32)                                                  # what component mode is handed
 
 
+def reference_outputs():
+    """tests/golden/edge_cases.npz: what the REFERENCE ITSELF returns for this table (make_golden.py save_edge_cases);
+    refuses a fixture that was made for another version of the table."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "edge_cases.npz"))
+    assert [str(x) for x in z["names"]] == NAMES and np.array_equal(z["state"], STATE) and np.array_equal(z["params"], PARAMS) \
+        and np.array_equal(z["prev"], PREV), "edge_cases.npz is stale: python3 -B tests/golden/make_golden.py --only-ties"
+    return {k: z[k] for k in z.files}
+
+
 def check(f, t, ratio=None, comps=None, comp_ratio=None):
     """f, t: (n,3) net wrench of the fused entries.  comps: (n,8,3) + comp_ratio (n,) of component mode evaluated with
-    ACCEL32 as the accelerations (reference order: buoyancy F, drag F, lift F, drag T, added-mass F, added-mass T, cob, cop)."""
+    ACCEL32 as the accelerations (reference order: buoyancy F, drag F, lift F, drag T, added-mass F, added-mass T, cob, cop).
+    Checked against the oracle AND against the reference's own outputs for this table (reference_outputs)."""
     from oracle import hydro_oracle as ho
     with np.errstate(all="ignore"):
         rf, rt, aux = ho.step_wrench(STATE, PREV, PARAMS, RHO, G, DT)
+    fx = reference_outputs()
+    for i, name in enumerate(NAMES):                            # the oracle is what the reference does, case by case
+        scale = max(1.0, np.abs(fx["net_force"][i]).max(), np.abs(fx["net_torque"][i]).max())
+        assert np.abs(rf[i] - fx["net_force"][i]).max() <= 1e-12 * scale and np.abs(rt[i] - fx["net_torque"][i]).max() <= 1e-12 * scale, name
+        assert aux["ratio"][i] == fx["ratio"][i], name
     assert np.isfinite(f).all() and np.isfinite(t).all()
     for i, name in enumerate(NAMES):
         tol_f = 1e-6 * max(1.0, np.abs(rf[i]).max())
@@ -127,6 +143,10 @@ def check(f, t, ratio=None, comps=None, comp_ratio=None):
             # a centre is p + arm evaluated in fp64 and rounded to fp32 once: half an fp32 ulp of the coordinate
             tol = 0.5 * np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64) * (1 + 1e-6) + 1e-12
             assert np.all(np.abs(comps[i, k] - ref) <= tol), (name, fld, comps[i, k], ref)
+        for k in (0, 1, 2, 3, 6, 7):                            # everything but the added mass is independent of the accelerations:
+            want = fx["components"][i, k]                        # straight against the reference's own numbers
+            tol = 1e-6 * scale if k < 6 else 0.5 * np.spacing(np.abs(want).astype(np.float32)).astype(np.float64) * (1 + 1e-6) + 1e-12
+            assert np.all(np.abs(comps[i, k] - want) <= tol), (name, k, comps[i, k], want)
         if c["ratio"][i] == 0.0:
             assert np.all(comps[i] == 0.0), name                      # Numba: zeros for everything, centres included (N6)
         if comp_ratio is not None:

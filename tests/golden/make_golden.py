@@ -343,12 +343,31 @@ def save_ties():
     print(f"  row 0 (VERDICT r3 body): net_T {net_t[0]}  cob {comps[0, 6]}")
 
 
+def save_edge_cases():
+    """The degenerate-input table of tests/edge_cases.py (zero dimensions / mass / speed, -0.0, clamp, 10 km offsets, every
+    surface tie under four orientations) through the reference itself: the edge-case tests then compare the kernels with
+    what the REFERENCE returns for these inputs, not only with the oracle's restatement of it."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import edge_cases as ec
+    with np.errstate(all="ignore"):
+        comps, ratio, rest = reference_batch(ec.STATE, ec.ACCEL, ec.PARAMS, ec.RHO, ec.G)
+        net_f, net_t = reference_behavior_batch(ec.STATE, ec.PREV, ec.PARAMS, ec.RHO, ec.G, ec.DT)
+    assert np.isfinite(comps).all() and np.isfinite(net_f).all() and np.isfinite(net_t).all()
+    path = os.path.join(HERE, "edge_cases.npz")
+    np.savez_compressed(path, names=np.array(ec.NAMES), state=ec.STATE, prev=ec.PREV, params=ec.PARAMS, rho=np.float64(ec.RHO),
+                        g=np.float64(ec.G), dt=np.float64(ec.DT), components=comps, ratio=ratio, rest_completed=rest,
+                        net_force=net_f, net_torque=net_t)
+    print(f"edge_cases: {len(ec.NAMES)} cases, rest-completed {int(rest.sum())}, dry {int((ratio == 0).sum())} -> {os.path.getsize(path)} B")
+
+
 def main():
     from silver2_isaacsim_amd import scenes
     if "--only-ties" in sys.argv:
-        return save_ties()
+        save_ties()
+        return save_edge_cases()
     save_known_answers()
     save_ties()
+    save_edge_cases()
     sc = scenes.scene_c2()
     save_scene_fixture("c2", sc, np.arange(sc.n))
     sc = scenes.scene_c3()

@@ -724,7 +724,9 @@ def test_batched_launch_refuses_what_one_kernel_instance_cannot_serve(native_bui
         HydroEngine.step_wrench_tiled_batch([a, b], [st, st], 0.0, prevs=[pv, pv])
     empty = HydroEngine(n, DEV)                                                             # no parameters set
     with pytest.raises(HydroError, match="HYDRO_E_STATE"):
-        HydroEngine.step_wrench_tiled_batch([a, empty], [st, st], dt, prevs=[pv, pv])
+        HydroEngine.step_wrench_tiled_batch([a, empty], [st, st], dt, prevs=[pv, pv], ns=[n, n])
+    with pytest.raises(HydroError, match="empty scene"):
+        HydroEngine.step_wrench_tiled_batch([a, b], [st, st], dt, prevs=[pv, pv], ns=[n, 0])
     for e in (a, b, c, empty):
         e.close()
 
