@@ -509,26 +509,54 @@ struct BatchScene {
     uint32_t n, pad;
     double rho, g;
 };
+// K = capacity of the kernarg table.  K = 4 (launches of up to four scenes): all four descriptors arrive with the FIRST
+// round of scalar loads and the block's own is picked with scalar selects - one scalar-memory round trip before the first
+// vector load instead of two (table, then descriptor); K = HYDRO_BATCH_MAX: the descriptor is loaded by index.
+template <int K>
 struct BatchArgs {
-    uint32_t first_block[HYDRO_BATCH_MAX];      // first block of scene s in the grid (0xffffffff beyond the last scene)
-    BatchScene sc[HYDRO_BATCH_MAX];
+    uint32_t first_block[K];                    // first block of scene s in the grid (0xffffffff beyond the last scene)
+    BatchScene sc[K];
     double inv_dt;
 };
+template <typename T> __device__ __forceinline__ T pick(bool c, T x, T y) { return c ? x : y; }
 
-template <bool HALF, bool WRITE_PREV, bool NT, bool WARP>
-__global__ void __launch_bounds__(kBlock) HYDRO_TILED_OCC_ATTR wrench_tiled_batch_kernel(const BatchArgs args)
+template <int K, bool HALF, bool WRITE_PREV, bool NT, bool WARP>
+__global__ void __launch_bounds__(kBlock) HYDRO_TILED_OCC_ATTR wrench_tiled_batch_kernel(const BatchArgs<K> args)
 {
     // first_block is increasing (0xffffffff beyond the last scene): the last j with first_block[j] <= block is the scene.
     // Everything here is uniform over the block - compares and selects on the scalar unit.
     const uint32_t bid = __builtin_amdgcn_readfirstlane(blockIdx.x);
-    uint32_t scene = 0;
+    uint32_t scene = 0, first = args.first_block[0];
 #pragma unroll
-    for (int j = 1; j < HYDRO_BATCH_MAX; ++j) scene = (bid >= args.first_block[j]) ? (uint32_t)j : scene;
-    const BatchScene& b = args.sc[scene];
+    for (int j = 1; j < K; ++j) {
+        const bool here = bid >= args.first_block[j];
+        scene = here ? (uint32_t)j : scene;
+        first = here ? args.first_block[j] : first;
+    }
+    BatchScene b;
+    if constexpr (K <= 4) {
+        // what a wave needs before its first vector load, of ALL K scenes, asked for here: the scalar loads then go out
+        // together with the table's (the compiler would otherwise sink them below the early exit: a second round trip)
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            asm volatile("" : : "s"(args.sc[j].st), "s"(args.sc[j].pv), "s"(args.sc[j].prm), "s"(args.sc[j].st_stride), "s"(args.sc[j].pv_stride), "s"(args.sc[j].n));
+        b = args.sc[0];
+#pragma unroll
+        for (int j = 1; j < K; ++j) {
+            const bool m = scene == (uint32_t)j;
+            const BatchScene& o = args.sc[j];
+            b.st = pick(m, o.st, b.st); b.pv = pick(m, o.pv, b.pv); b.prm = pick(m, o.prm, b.prm); b.out = pick(m, o.out, b.out);
+            b.pv_out = pick(m, o.pv_out, b.pv_out); b.st_stride = pick(m, o.st_stride, b.st_stride); b.pv_stride = pick(m, o.pv_stride, b.pv_stride);
+            b.out_stride = pick(m, o.out_stride, b.out_stride); b.pvo_stride = pick(m, o.pvo_stride, b.pvo_stride);
+            b.n = pick(m, o.n, b.n); b.rho = pick(m, o.rho, b.rho); b.g = pick(m, o.g, b.g);
+        }
+    } else {
+        b = args.sc[scene];
+    }
     TiledArgs a;
     a.st = b.st; a.st_stride = b.st_stride; a.pv = b.pv; a.pv_stride = b.pv_stride; a.pv_out = b.pv_out; a.pvo_stride = b.pvo_stride;
     a.prm = b.prm; a.out = b.out; a.out_stride = b.out_stride; a.rho = b.rho; a.g = b.g; a.inv_dt = args.inv_dt; a.warp = WARP; a.n = b.n;
-    const uint32_t i = (bid - args.first_block[scene]) * kBlock + threadIdx.x;
+    const uint32_t i = (bid - first) * kBlock + threadIdx.x;
     if (i >= a.n) return;
     const uint32_t tile = i >> 6, lane = i & 63u;
     const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
@@ -1759,7 +1787,7 @@ int hydro_step_wrench_tiled_batch(int count, const hydro_scene_t* scenes, double
     hydro_engine* h0 = scenes[0].engine;                       // errors are reported on the first scene's handle
     if (!(dt > 0.0)) return fail(h0, HYDRO_E_ARG, "dt must be > 0");
     const bool own_prev = (scenes[0].prev == nullptr);
-    BatchArgs args;
+    BatchArgs<HYDRO_BATCH_MAX> args;
     int64_t blocks = 0, bodies = 0;
     for (int k = 0; k < HYDRO_BATCH_MAX; ++k) args.first_block[k] = 0xffffffffu;
     for (int k = 0; k < count; ++k) {
@@ -1802,13 +1830,20 @@ int hydro_step_wrench_tiled_batch(int count, const hydro_scene_t* scenes, double
         }
     const bool nt = h0->nt < 0 ? (bodies >= kNtMinBodies) : (h0->nt != 0);       // streaming accesses by the size of the LAUNCH
     const dim3 grid((uint32_t)blocks), blk(kBlock);
-#define HYDRO_BATCH_W(HALF, WP, NT) do { if (h0->semantics) hipLaunchKernelGGL((wrench_tiled_batch_kernel<HALF, WP, NT, true>), grid, blk, 0, s, args); \
-                                         else hipLaunchKernelGGL((wrench_tiled_batch_kernel<HALF, WP, NT, false>), grid, blk, 0, s, args); } while (0)
+    BatchArgs<4> small;                                          // up to four scenes: the short table (see the kernel)
+    if (count <= 4) {
+        for (int k = 0; k < 4; ++k) { small.first_block[k] = args.first_block[k]; small.sc[k] = args.sc[k < count ? k : 0]; }
+        small.inv_dt = args.inv_dt;
+    }
+#define HYDRO_BATCH_K(HALF, WP, NT, W) do { if (count <= 4) hipLaunchKernelGGL((wrench_tiled_batch_kernel<4, HALF, WP, NT, W>), grid, blk, 0, s, small); \
+                                            else hipLaunchKernelGGL((wrench_tiled_batch_kernel<HYDRO_BATCH_MAX, HALF, WP, NT, W>), grid, blk, 0, s, args); } while (0)
+#define HYDRO_BATCH_W(HALF, WP, NT) do { if (h0->semantics) HYDRO_BATCH_K(HALF, WP, NT, true); else HYDRO_BATCH_K(HALF, WP, NT, false); } while (0)
 #define HYDRO_BATCH_NT(HALF, WP) do { if (nt) HYDRO_BATCH_W(HALF, WP, true); else HYDRO_BATCH_W(HALF, WP, false); } while (0)
     if (h0->half_coeffs) { if (own_prev) HYDRO_BATCH_NT(true, true); else HYDRO_BATCH_NT(true, false); }
     else { if (own_prev) HYDRO_BATCH_NT(false, true); else HYDRO_BATCH_NT(false, false); }
 #undef HYDRO_BATCH_NT
 #undef HYDRO_BATCH_W
+#undef HYDRO_BATCH_K
     HYDRO_HIP(h0, hipGetLastError(), HYDRO_E_LAUNCH);
     return HYDRO_OK;
 }
