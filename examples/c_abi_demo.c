@@ -93,6 +93,38 @@ int main(int argc, char **argv)
     CHECK_HIP(hipMemcpy(w2, d_out2, sizeof(float) * n * 6, hipMemcpyDeviceToHost));
     if (memcmp(w, w2, sizeof(float) * n * 6) != 0) { fprintf(stderr, "tiled and plain-SoA entries disagree\n"); return 5; }
 
+    /* several independent scenes in ONE launch (hydro_step_wrench_tiled_batch): here the same scene twice, into two
+     * wrench buffers - each must carry the bits of the single launch above */
+    {
+        float *t_out_a, *t_out_b;
+        const size_t wbytes = sizeof(float) * tiles * 6 * HYDRO_TILE;
+        CHECK_HIP(hipMalloc((void **)&t_out_a, wbytes)); CHECK_HIP(hipMalloc((void **)&t_out_b, wbytes));
+        hydro_scene_t scenes[2];
+        for (int k = 0; k < 2; ++k) {
+            scenes[k].engine = h; scenes[k].n = n;
+            scenes[k].state = t_state; scenes[k].state_tile_stride = 13 * HYDRO_TILE;
+            scenes[k].prev = t_prev; scenes[k].prev_tile_stride = 6 * HYDRO_TILE;
+            scenes[k].wrench = k ? t_out_b : t_out_a; scenes[k].wrench_tile_stride = 6 * HYDRO_TILE;
+        }
+        CHECK_HYDRO(h, hydro_step_wrench_tiled_batch(2, scenes, dt, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        float *ref = malloc(wbytes), *ga = malloc(wbytes), *gb = malloc(wbytes);
+        CHECK_HIP(hipMemcpy(ref, t_out, wbytes, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(ga, t_out_a, wbytes, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(gb, t_out_b, wbytes, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i)
+            for (int f = 0; f < 6; ++f) {
+                const size_t at = (size_t)(i / HYDRO_TILE) * 6 * HYDRO_TILE + (size_t)f * HYDRO_TILE + (size_t)(i % HYDRO_TILE);
+                if (memcmp(&ref[at], &ga[at], sizeof(float)) != 0 || memcmp(&ref[at], &gb[at], sizeof(float)) != 0) {
+                    fprintf(stderr, "batched launch and single launch disagree at body %lld field %d\n", (long long)i, f); return 9;
+                }
+            }
+        if (hydro_step_wrench_tiled_batch(0, scenes, dt, stream) != HYDRO_E_ARG || hydro_step_wrench_tiled_batch(HYDRO_BATCH_MAX + 1, scenes, dt, stream) != HYDRO_E_ARG) return 9;
+        fprintf(stderr, "batched launch: 2 scenes in one launch, bit-identical to the single launch\n");
+        free(ref); free(ga); free(gb);
+        CHECK_HIP(hipFree(t_out_a)); CHECK_HIP(hipFree(t_out_b));
+    }
+
     double ke[2];
     double *d_ke;
     CHECK_HIP(hipMalloc((void **)&d_ke, sizeof ke));

@@ -16,8 +16,10 @@
 //   * nothing re-read and nothing written but the wrench (24 B per body).
 // The array-of-structs entry (the simulator's tensor layout) reads and writes one row per lane with 12- and 16-byte
 // accesses (LDS staging of the transposition was measured and lost: DESIGN.md section 5); the kinetic-energy
-// reduction - stand-alone, or fused into the wrench / step kernels for the bodies already in registers - uses wave64
-// shuffles, LDS across the block's four waves and a fixed-order second stage.
+// reduction - stand-alone, or fused into the wrench / step kernels for the bodies already in registers - is where lanes
+// exchange data: LDS across the block's four waves, wave64 DPP butterflies, and integer tickets that let ONE launch
+// finish the fixed-order sum (see "kinetic-energy reduction" below).  One code path per kernel: the forms that were
+// measured and rejected live in scripts/ab/.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <dlfcn.h>
@@ -1787,7 +1789,7 @@ int hydro_step_wrench_tiled_batch(int count, const hydro_scene_t* scenes, double
     hydro_engine* h0 = scenes[0].engine;                       // errors are reported on the first scene's handle
     if (!(dt > 0.0)) return fail(h0, HYDRO_E_ARG, "dt must be > 0");
     const bool own_prev = (scenes[0].prev == nullptr);
-    BatchArgs<HYDRO_BATCH_MAX> args;
+    BatchArgs<HYDRO_BATCH_MAX> args{};
     int64_t blocks = 0, bodies = 0;
     for (int k = 0; k < HYDRO_BATCH_MAX; ++k) args.first_block[k] = 0xffffffffu;
     for (int k = 0; k < count; ++k) {
@@ -1830,7 +1832,7 @@ int hydro_step_wrench_tiled_batch(int count, const hydro_scene_t* scenes, double
         }
     const bool nt = h0->nt < 0 ? (bodies >= kNtMinBodies) : (h0->nt != 0);       // streaming accesses by the size of the LAUNCH
     const dim3 grid((uint32_t)blocks), blk(kBlock);
-    BatchArgs<4> small;                                          // up to four scenes: the short table (see the kernel)
+    BatchArgs<4> small{};                                        // up to four scenes: the short table (see the kernel)
     if (count <= 4) {
         for (int k = 0; k < 4; ++k) { small.first_block[k] = args.first_block[k]; small.sc[k] = args.sc[k < count ? k : 0]; }
         small.inv_dt = args.inv_dt;

@@ -44,6 +44,7 @@ def test_plain_c_host_program(tmp_path, native_built):
     assert err.max() <= 1e-5
     assert "bit-identical to the eager loop" in run.stderr                         # 64 fused steps from a HIP graph, from C
     assert "resident loop: 63 + 1 steps in two launches, bit-identical" in run.stderr  # hydro_step_fused_tiled_multi from C
+    assert "batched launch: 2 scenes in one launch, bit-identical" in run.stderr       # hydro_step_wrench_tiled_batch from C
     assert "global kinetic energy over 1 rank(s) through RCCL" in run.stderr          # hydro_ke_allreduce: SURVEY.md 8e, from C
     ke_line = [l for l in run.stderr.splitlines() if l.startswith("kinetic energy")][0]
     lin = float(ke_line.split()[2])
