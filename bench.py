@@ -511,7 +511,7 @@ def closed_loop_rate(kind: str, n: int, steps: int = 4096, fused: bool = True, i
     in registers (hydro_step_fused_tiled_multi; same bits) - no HBM traffic and no launch between the steps."""
     from silver2_isaacsim_amd.simulate import ClosedLoopSim
     sim = ClosedLoopSim(build_scene(kind, n, 17), fused=fused, implicit_drag=implicit_drag)
-    r = sim.measure_rtf(steps, graph_steps=64, resident=resident)
+    r = sim.measure_rtf(steps, graph_steps=64, resident=resident, warm_seconds=0.25)      # sustained rate, as the headline's spin-up
     sim.close()
     mode = "hipGraph x64 (hydro_step_fused_tiled)" if fused else "hipGraph x64 (wrench_tiled + integrate_tiled)"
     if resident:
@@ -1076,7 +1076,7 @@ def main():
             guarded("closed_loop_c2_4096_resident", closed_loop_rate, "c2", 4096, resident=True)
             guarded("closed_loop_c3_1024envs_implicit_resident", closed_loop_rate, "c3", 19456, implicit_drag=True, resident=True)
             guarded("closed_loop_c2_262144_resident", closed_loop_rate, "c2", 262144, steps=1024, resident=True)
-            guarded("closed_loop_c2_1048576_resident", closed_loop_rate, "c2", 1048576, steps=512, resident=True)
+            guarded("closed_loop_c2_1048576_resident", closed_loop_rate, "c2", 1048576, steps=2560, resident=True)
             # the compute-bound entries also get the fraction at the clock this box held under SUSTAINED arithmetic (64 passes per wave)
             held = ex.get("clocks_1m", {}).get("sustained_arithmetic_ghz") if isinstance(ex.get("clocks_1m"), dict) else None
             for v in ex.values():

@@ -277,12 +277,18 @@ class ClosedLoopSim:
         self.synchronize()
         return ke.cpu().numpy()
 
-    def measure_rtf(self, steps: int, graph_steps: int = 64, resident: bool = False) -> dict:
+    def measure_rtf(self, steps: int, graph_steps: int = 64, resident: bool = False, warm_seconds: float = 0.0) -> dict:
         """Real-time factor the way benchmark_rtf.py:48-71 defines it: sim time / wall time.
-        resident=True: run_resident with chunk = graph_steps instead of graph replays of single steps."""
+        resident=True: run_resident with chunk = graph_steps instead of graph replays of single steps.
+        warm_seconds: keep stepping untimed for that long first (a GPU coming out of idle needs ~50 ms to reach the clock
+        it then holds; a timed region of a few milliseconds right after one warm launch measures the ramp)."""
         go = (lambda k: self.run_resident(k, graph_steps or 64)) if resident else (lambda k: self.run(k, graph_steps))
         go(graph_steps or 2)                            # capture + warm
         self.synchronize()
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < warm_seconds:
+            go(graph_steps or 2)
+            self.synchronize()
         t0 = time.perf_counter()
         go(steps)
         self.synchronize()
