@@ -497,7 +497,9 @@ def valu_roofline(kernel_prefix: str, n: int, us_per_step: float, clock_held_ghz
            "achieved": kernels[key]["valu_total"] * (n / 64) / (us_per_step * 1e-6) / 1e9,
            "peak": SIMDS * PEAK_CLOCK_GHZ / 4.0, "unit": "G wave-instructions/s (peak: 4-cycle instructions at 2.4 GHz)",
            "frac": busy_us_at_peak / us_per_step,
-           "frac_is": "issue cycles of the step's VALU instructions (priced per class) / cycles of 1 024 SIMDs at 2.4 GHz in the measured time"}
+           "frac_is": "issue cycles of the step's VALU instructions (priced per class with scripts/ubench_valu.hip) / cycles of 1 024 SIMDs at the "
+                      "2.4 GHz spec clock in the measured time; ~1.0 = VALU-issue bound at the spec clock (the chip reads up to 2.55 GHz "
+                      "in-kernel under arithmetic alone, so a percent or two above 1 is that boost, not an error)"}
     if clock_held_ghz:
         out["clock_held_ghz"] = clock_held_ghz
         out["frac_at_clock_held"] = busy_us_at_peak * PEAK_CLOCK_GHZ / clock_held_ghz / us_per_step
