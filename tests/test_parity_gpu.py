@@ -941,6 +941,25 @@ def test_surface_ties_through_every_entry(native_built):
     assert ho.wrench_error(f16, t16, rf, rt, p16, rho, g).max() <= GATE
 
 
+def test_quantised_fuzz_on_device(native_built):
+    """The 200 000-body quantised population of tests/test_numerics_host.py::test_quantised_fuzz_host (another seed) on the
+    DEVICE, whose reciprocals and roots are the seeded forms: wrench within the gate, ratio, and the calculator surface
+    (centres to half an fp32 ulp) - every exact tie of the model decided as the reference decides it."""
+    import populations
+    from test_numerics_host import check_components
+    st, pv, pr, kind = populations.surface_ties(n=200000, seed=777)
+    f, t = run_ext(st, pv, pr, populations.RHO, populations.G, populations.DT)
+    rf, rt, aux = ho.step_wrench(st, pv, pr, populations.RHO, populations.G, populations.DT)
+    err = ho.wrench_error(f, t, rf, rt, pr, populations.RHO, populations.G)
+    assert err.max() <= GATE, f"{(err > GATE).sum()} bodies above the gate, max {err.max():.3e}"
+    dry = aux["ratio"] == 0.0
+    assert np.all(f[dry] == 0.0) and np.all(t[dry] == 0.0)
+    acc32 = ((st[:, 7:13].astype(np.float64) - pv.astype(np.float64)) / populations.DT).astype(np.float32)
+    comps, ratio = _components_both_entries(st, acc32, pr, populations.RHO, populations.G)
+    ref = ho.solve_components(st, acc32.astype(np.float64), pr.astype(np.float64), populations.RHO, populations.G)
+    check_components(comps, ratio, ref)
+
+
 def test_engine_lifetime_does_not_leak(native_built):
     """on_play / on_stop cycles create and drop engines: device memory must come back."""
     fx = load_golden("c2")
