@@ -127,4 +127,11 @@ for k in (6, 7):
     for i in np.where(b)[0][:4]:
         print("    centre", k, i, state[i], params[i], out[i, k], want[i])
 print(f"kernel arithmetic vs reference (cob / cop): {nb} bodies outside half an fp32 ulp + 1e-6")
+nf = 0
+for k in (0, 1, 2, 3):                                            # buoyancy, drag force, lift, drag torque: independent of the accelerations
+    b = finite & (np.abs(out[:, k] - comps[:, k]).max(axis=1) > 1e-6 * scale)
+    nf += b.sum()
+    for i in np.where(b)[0][:4]:
+        print("    component", k, i, state[i], params[i], out[i, k], comps[i, k])
+print(f"kernel arithmetic vs reference (buoyancy, drag force, lift, drag torque): {nf} bodies beyond 1e-6 of the body's largest term")
 print(f"ratio: max |diff| {np.nanmax(np.where(finite, np.abs(rr - ratio), 0)):.3e}")
