@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 
 #include "../../include/hydro.h"
@@ -2185,13 +2186,11 @@ typedef int (*nccl_all_reduce_fn)(const void*, void*, size_t, int, int, void*, h
 typedef const char* (*nccl_error_string_fn)(int);
 nccl_all_reduce_fn g_nccl_all_reduce = nullptr;
 nccl_error_string_fn g_nccl_error_string = nullptr;
-bool g_nccl_tried = false;
+std::once_flag g_nccl_once;                           // (handles are independent across host threads: bind once, whoever comes first)
 constexpr int kNcclFloat64 = 8, kNcclSum = 0;        // rccl.h: ncclDataType_t / ncclRedOp_t
 
-bool bind_rccl()
+bool bind_rccl_once()
 {
-    if (g_nccl_tried) return g_nccl_all_reduce != nullptr;
-    g_nccl_tried = true;
     void* lib = nullptr;
     const char* named = getenv("HYDRO_RCCL_LIBRARY");
     void* sym = named ? nullptr : dlsym(RTLD_DEFAULT, "ncclAllReduce");
@@ -2205,8 +2204,14 @@ bool bind_rccl()
         if (!lib) return false;
         sym = dlsym(lib, "ncclAllReduce");
     }
-    g_nccl_all_reduce = reinterpret_cast<nccl_all_reduce_fn>(sym);
     g_nccl_error_string = reinterpret_cast<nccl_error_string_fn>(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    g_nccl_all_reduce = reinterpret_cast<nccl_all_reduce_fn>(sym);
+    return g_nccl_all_reduce != nullptr;
+}
+
+bool bind_rccl()
+{
+    std::call_once(g_nccl_once, [] { (void)bind_rccl_once(); });
     return g_nccl_all_reduce != nullptr;
 }
 }  // namespace
