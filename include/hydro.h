@@ -42,8 +42,10 @@ extern "C" {
  *        hydro_reserve_soa; the engine holds 68 B per body and makes its plain-SoA copies on first use
  * 0.5.0: hydro_step_fused_tiled_multi (any number of closed-loop steps in one pass, the bodies stay in registers)
  * 0.6.0: hydro_step_wrench_tiled_batch (several independent scenes in one launch); the kinetic-energy entries are one
- *        launch (the final sum happens in the block that finishes last); hydro_ke_allreduce (RCCL from C) */
-#define HYDRO_VERSION 0x000600
+ *        launch (the final sum happens in the block that finishes last); hydro_ke_allreduce (RCCL from C)
+ * 0.7.0: hydro_ke_rearm, hydro_bind_rccl / hydro_rccl_origin, hydro_debug_ke_fault; a kinetic-energy launch that does not
+ *        finish leaves NaNs, never a stale pair; hydro_step_wrench validates before it allocates */
+#define HYDRO_VERSION 0x000700
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
@@ -167,7 +169,10 @@ int hydro_step_wrench_tiled(hydro_t *h, int64_t n, const float *state, int64_t s
  * hydrodynamics_behavior.py:131-138,176-238) when the environments live in separate buffers.
  * One kernel instance serves the launch, so all scenes share: the device, the coefficient format (f32 / f16), the
  * semantics, the previous-velocity mode (all prev == NULL or none), and dt.  Scene scalars (rho, g) may differ.  An
- * engine that owns the previous velocity may appear once per launch.  Errors are reported on scenes[0].engine. */
+ * engine that owns the previous velocity may appear once per launch.  Errors are reported on scenes[0].engine; the
+ * hydro_set_tuning knobs that apply (non_temporal) are those of scenes[0].engine, by the size of the whole launch.
+ * Everything is validated for every scene before anything is launched; a failure of the launch itself may leave the
+ * engine-owned previous velocities of some scenes marked as "tiled copy current", which is always truthful. */
 typedef struct hydro_scene {
     hydro_t *engine;
     int64_t n;
@@ -235,7 +240,14 @@ int hydro_step_components_aos(hydro_t *h, int64_t n, const float *position, cons
  * RCCL.  New functionality named by BASELINE.json north_star; absent from the reference.
  * These are the stand-alone entries (one pass over the state: 56 B per body with the rotational term);
  * hydro_step_wrench_tiled_ke / hydro_step_fused_tiled_ke sample the same pair, same bits, inside a step.
- * All of them use the engine's reduction scratch: do not overlap two of them on one engine (two streams). */
+ * All of them use the engine's reduction scratch (partials + integer ticket counters that a launch leaves at zero).
+ * Two of them on one engine must not be in flight at once: a launch on a stream other than the previous one's is
+ * ordered behind it by the library (an event wait on the device; not while either stream is being captured - keep a
+ * captured graph's kinetic-energy launches on one stream).
+ * A result is never stale: block 0 of every launch first overwrites out_dev[0..1] with NaNs, and only the wavefront that
+ * completes the sum replaces them - a launch that did not run to its end (device reset, aborted graph) leaves NaNs.
+ * After such an event the counters may be non-zero: hydro_ke_rearm zeroes them (the library does so by itself before the
+ * next kinetic-energy launch whenever a HIP call on this handle has reported an error). */
 int hydro_kinetic_energy(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], int rotational,
                          double *out_dev, void *stream);
 int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride, int rotational,
@@ -248,6 +260,27 @@ int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_
  * HYDRO_RCCL_LIBRARY overrides), so a single-GPU host needs no RCCL; HYDRO_E_STATE if there is none.  New functionality
  * named by BASELINE.json north_star; the reference has no reduction of any kind. */
 int hydro_ke_allreduce(hydro_t *h, void *nccl_comm, double *ke_dev, void *stream);
+
+/* Which RCCL hydro_ke_allreduce calls.  A communicator belongs to ONE loaded copy of the library (a Python host's torch
+ * ships its own), so the safe binding is the caller's: hydro_bind_rccl((void *)ncclAllReduce, (void *)ncclGetErrorString)
+ * hands over the functions of the copy that made the communicator (the second may be NULL).  Without it the first
+ * hydro_ke_allreduce looks one up: HYDRO_RCCL_LIBRARY if set (that or nothing), else the copy already loaded in the
+ * process, else the system librccl; only success is remembered, a failed look-up is repeated by the next call.
+ * hydro_bind_rccl(NULL, NULL) forgets the binding.  Process-wide, thread-safe.  hydro_rccl_origin() says where the
+ * current binding came from ("unbound", "hydro_bind_rccl", "HYDRO_RCCL_LIBRARY", ...). */
+int hydro_bind_rccl(void *nccl_all_reduce, void *nccl_get_error_string);
+const char *hydro_rccl_origin(void);
+
+/* Zero the ticket counters of the kinetic-energy reduction on `stream` (see hydro_kinetic_energy): the recovery path
+ * after a launch that did not finish.  Harmless at any other time, provided no kinetic-energy launch of this engine is
+ * in flight on another stream. */
+int hydro_ke_rearm(hydro_t *h, void *stream);
+
+/* TEST HOOK, not for production use: after a device synchronisation, write `value` into ticket counter `counter`
+ * (0 = the top counter, 1 + c = class c) - the state an aborted launch leaves behind - and, if as_failed_launch, mark the
+ * handle the way a failed HIP call does, so that the next kinetic-energy launch re-arms by itself
+ * (tests/test_error_paths_gpu.py). */
+int hydro_debug_ke_fault(hydro_t *h, int counter, uint32_t value, int as_failed_launch);
 
 /* Explicit rigid-body step standing in for PhysX in closed-loop runs:
  * semi-implicit Euler with gravity and box inertia.  state_out may alias state_in. */

@@ -75,6 +75,10 @@ SIGNATURES = {
     "hydro_kinetic_energy": (c_int, [c_void_p, c_int64, _FP, c_int, c_void_p, c_void_p]),
     "hydro_kinetic_energy_tiled": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hydro_ke_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hydro_bind_rccl": (c_int, [c_void_p, c_void_p]),
+    "hydro_rccl_origin": (c_char_p, []),
+    "hydro_ke_rearm": (c_int, [c_void_p, c_void_p]),
+    "hydro_debug_ke_fault": (c_int, [c_void_p, c_int, ctypes.c_uint32, c_int]),
     "hydro_integrate": (c_int, [c_void_p, c_int64, _FP, _FP, c_double, _FP, c_void_p]),
     "hydro_set_tuning": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
     "hydro_sync": (c_int, [c_void_p]),

@@ -499,14 +499,18 @@ class KitHost:
     """Binds the `SimHost` protocol to Omniverse Kit / Isaac Sim.  Imports are lazy so
     that this module loads without `omni`, `pxr`, `carb` (none exist outside Kit)."""
 
-    def __init__(self, device: str = "cuda:0", config_dir: str | None = None, use_builtin_table: bool = False):
+    def __init__(self, device: str = "cuda:0", config_dir: str | None = None, use_builtin_table: bool | None = None):
         """config_dir: where hydrodynamics_config.json is looked for - the directory of the SCRIPTED behaviour file in
-        the reference (hydrodynamics_behavior.py:76-77); pass that directory (default: this package's).
-        use_builtin_table: with no JSON there, apply the table the reference ships (config.default_config()) instead
-        of the reference's rule, which is to warn and keep the USD values (:79-81)."""
+        the reference (hydrodynamics_behavior.py:76-77).
+        use_builtin_table: with no JSON there, apply the table the reference ships (config.default_config(), the values
+        of hydrodynamics_config.json:2-54) instead of the reference's rule for a missing file, which is to warn and keep
+        the USD values (:79-81).  Default: True when no config_dir is given, False for an explicit one.  The reference
+        always HAS its JSON beside the script, so out of the box it applies the globals and the per-part table (:76-101);
+        a default `KitHost()` must run with the same physical parameters, and this package ships the table as
+        constants (config.py), not as a file.  A host that names a directory gets the literal rule for it."""
         self.device = device
         self._config_dir = config_dir or os.path.dirname(os.path.abspath(__file__))
-        self._use_builtin_table = bool(use_builtin_table)
+        self._use_builtin_table = (config_dir is None) if use_builtin_table is None else bool(use_builtin_table)
         self._sim_context = None
 
     def ensure_simulation_context(self):
@@ -574,7 +578,8 @@ class KitHost:
     def config_path(self):
         # The reference's rule (:76-81): the JSON beside the script is applied; if there is none, a warning, and the
         # USD attribute values stay as they are (cfg.load_config does exactly that for a path that does not exist).
-        # Only a host that ASKED for it (use_builtin_table=True) gets the shipped table in that case (path None).
+        # A host that ASKED for it (use_builtin_table=True), or that named no directory at all (the default deployment:
+        # the reference's script always has its JSON next to it), gets the shipped table in that case (path None).
         p = os.path.join(self._config_dir, cfg.CONFIG_FILE_NAME)
         if self._use_builtin_table and not os.path.exists(p):
             return None

@@ -199,7 +199,12 @@ __device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t
 // What the tail costs: ~0.75 us per ticket whose result is waited for, ~0.2 us per published value, i.e. ~2.5 us after the
 // last block's bodies have arrived; a second launch for the final sum cost 4 us.
 // The counters are reset by the wavefronts that finish, so a launch leaves them at 0: launches on one engine must not
-// overlap (a handle is not thread-safe anyway).
+// overlap (a handle is not thread-safe anyway; the host side orders a launch on a NEW stream behind the previous one, see
+// ke_prepare).  A launch that does not run to its end (a device reset, an aborted graph) leaves counters behind on which no
+// later launch draws the "last" ticket.  So that this cannot pass for a result, block 0 POISONS `out` with NaNs before it
+// draws its ticket - ordered before the final store through the ticket chain, both write-through - and only a launch
+// that finishes overwrites them; the host re-arms the counters (hydro_ke_rearm, and by itself after any HIP error seen
+// on the handle).
 // Scratch (doubles): [stride] translational partials | [stride] rotational | [64] + [64] class sums | counters (uint32, one
 // per 256 B): top, class 0 .. 63.
 // --------------------------------------------------------------------------
@@ -253,6 +258,10 @@ __device__ __forceinline__ void ke_block_reduce(double lin, double rot, double* 
     __shared__ double stage[2][kBlock];
     stage[0][threadIdx.x] = lin;
     stage[1][threadIdx.x] = rot;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                  // no result yet: NaNs until the last ticket of all replaces them
+        ke_publish(out, __builtin_nan(""));
+        ke_publish(out + 1, __builtin_nan(""));
+    }
     __syncthreads();
     if (threadIdx.x >= 64u) return;                              // waves 1-3 are done
     // ---- wave 0, all 64 lanes, no barrier from here on ----
@@ -295,7 +304,7 @@ __device__ __forceinline__ void ke_block_reduce(double lin, double rot, double* 
     b = l < classes ? ke_fetch(class_sums + kKeClasses + l) : 0.0;
     a = wave_sum(a);
     b = wave_sum(b);
-    if (l == 0) { out[0] = a; out[1] = b; }
+    if (l == 0) { ke_publish(out, a); ke_publish(out + 1, b); }
     ke_reset(counters);
 }
 
@@ -1179,6 +1188,13 @@ struct hydro_engine {
     bool soa_params_valid = false; // `params` / `coeffs16` reflect params_tiled
     double* ke_partials = nullptr; // [2][ke_stride]: one fp64 pair per block of 256 bodies
     uint32_t ke_stride = 0;
+    // The reduction's ticket counters are zero between launches that finish.  ke_suspect: something went wrong on this
+    // handle (a HIP call failed, or the caller says so: hydro_ke_rearm) - the next kinetic-energy launch zeroes them first.
+    // ke_last_stream: where the previous such launch went; a launch on ANOTHER stream is ordered behind it (ke_event).
+    bool ke_suspect = false;
+    bool ke_launched = false;
+    hipStream_t ke_last_stream = nullptr;
+    hipEvent_t ke_event = nullptr;
     hipStream_t stream = nullptr;
     int vec = 0;                   // bodies per lane, 0 = default (1)
     int block = 0;                 // threads per block, 0 = by size
@@ -1195,7 +1211,10 @@ namespace {
 int fail(hydro_engine* h, int code, const char* what, hipError_t e = hipSuccess)
 {
     if (h) {
-        if (e != hipSuccess) snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
+            h->ke_suspect = true;             // a launch of this handle may not have run to its end: re-arm the reduction
+        }
         else snprintf(h->err, sizeof h->err, "%s", what);
     }
     return code;
@@ -1263,8 +1282,12 @@ int ensure_soa_params(hydro_engine* h)
     if (!h->params && hipMalloc(&h->params, fbytes * HYDRO_PARAM_FIELDS) != hipSuccess)
         return fail(h, HYDRO_E_ALLOC, "plain-SoA parameter copy: allocation failed (first use of a plain-SoA entry point allocates; not inside a graph capture)");
     // (the fp16 copy is allocated with the fp32 one, whatever the current mode: hydro_set_params_f16 may come later)
-    if (!h->coeffs16 && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) != hipSuccess)
+    if (!h->coeffs16 && hipMalloc(&h->coeffs16, sizeof(__half) * (size_t)h->stride * 7) != hipSuccess) {
+        // both or neither: hydro_set_params_* refreshes the copies whenever `params` exists, and writes both
+        (void)hipFree(h->params);
+        h->params = nullptr; h->coeffs16 = nullptr; h->soa_params_valid = false;
         return fail(h, HYDRO_E_ALLOC, "plain-SoA fp16 coefficient copy: allocation failed");
+    }
     return h->soa_params_valid ? HYDRO_OK : refresh_soa_params(h);
 }
 
@@ -1352,6 +1375,20 @@ void launch_soa(hydro_engine* h, const SoaArgs& a, hipStream_t s)
     if constexpr (VEC > 1) {
         if (a.n > n_vec) launch_soa_n<1, WRITE_PREV>(h, shifted(a, n_vec, a.n - n_vec, h->half_coeffs), s, a.n);
     }
+}
+
+// the argument checks of a plain-SoA step that do not involve the previous velocity (shared by hydro_step_wrench, which must
+// pass them before it touches its own copy of it)
+int check_soa_step(hydro_engine* h, int64_t n, const float* const state[], double dt, float* const wrench[])
+{
+    int rc = check_common(h, n);
+    if (rc) return rc;
+    if (!state || !wrench) return fail(h, HYDRO_E_ARG, "null pointer table");
+    if (!(dt > 0.0)) return fail(h, HYDRO_E_ARG, "dt must be > 0");
+    if (n == 0) return HYDRO_OK;
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) if (!state[f]) return fail(h, HYDRO_E_ARG, "null state field");
+    for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) if (!wrench[f]) return fail(h, HYDRO_E_ARG, "null wrench field");
+    return HYDRO_OK;
 }
 
 template <bool WRITE_PREV>
@@ -1471,6 +1508,39 @@ int ke_of_nothing(hydro_engine* h, double* out_dev, hipStream_t s)
     return HYDRO_OK;
 }
 
+inline uint32_t* ke_counters(hydro_engine* h)
+{
+    return reinterpret_cast<uint32_t*>(h->ke_partials + 2 * (size_t)h->ke_stride + 2 * kKeClasses);
+}
+constexpr size_t kKeCounterBytes = (1 + kKeClasses) * 256;
+
+// Before every launch that carries the kinetic-energy reduction (stand-alone or inside a step kernel), on its stream:
+//   * the ticket counters are zeroed first if anything went wrong on this handle since the last one (ke_suspect);
+//   * a launch on a stream OTHER than the previous one's is ordered behind it - the scratch and the counters are the
+//     engine's, two reductions in flight at once would draw each other's tickets.  Costs nothing while the caller stays on
+//     one stream (a pointer compare).  Not done while either stream is being captured (an event from outside a capture
+//     cannot be waited for inside one): a captured launch on a second stream stays the caller's business, as documented.
+int ke_prepare(hydro_engine* h, hipStream_t s)
+{
+    if (h->ke_suspect) {
+        HYDRO_HIP(h, hipMemsetAsync(ke_counters(h), 0, kKeCounterBytes, s), HYDRO_E_LAUNCH);
+        h->ke_suspect = false;
+    }
+    if (h->ke_launched && s != h->ke_last_stream) {
+        hipStreamCaptureStatus c_new = hipStreamCaptureStatusNone, c_old = hipStreamCaptureStatusNone;
+        const bool known = hipStreamIsCapturing(s, &c_new) == hipSuccess && hipStreamIsCapturing(h->ke_last_stream, &c_old) == hipSuccess;
+        if (known && c_new == hipStreamCaptureStatusNone && c_old == hipStreamCaptureStatusNone) {
+            if (!h->ke_event && hipEventCreateWithFlags(&h->ke_event, hipEventDisableTiming) != hipSuccess) h->ke_event = nullptr;
+            if (h->ke_event && hipEventRecord(h->ke_event, h->ke_last_stream) == hipSuccess)
+                HYDRO_HIP(h, hipStreamWaitEvent(s, h->ke_event, 0), HYDRO_E_LAUNCH);
+        }
+        (void)hipGetLastError();               // (the previous stream may be gone: then there is nothing left to wait for)
+    }
+    h->ke_last_stream = s;
+    h->ke_launched = true;
+    return HYDRO_OK;
+}
+
 // Bring the copy of the engine-owned previous velocity that `want` names up to date (a repack
 // kernel on the caller's stream when the other layout was written last), then mark it as the one
 // that is about to be written.  The plain-SoA copy is allocated on its first use.
@@ -1561,6 +1631,7 @@ int hydro_destroy(hydro_t* h)
     if (h->params_tiled) (void)hipFree(h->params_tiled);
     if (h->prev_tiled) (void)hipFree(h->prev_tiled);
     if (h->ke_partials) (void)hipFree(h->ke_partials);
+    if (h->ke_event) (void)hipEventDestroy(h->ke_event);
     delete h;
     return HYDRO_OK;
 }
@@ -1682,13 +1753,13 @@ int hydro_set_prev_velocity(hydro_t* h, int64_t n, const float* const prev[HYDRO
 int hydro_step_wrench(hydro_t* h, int64_t n, const float* const state[HYDRO_STATE_FIELDS], double dt,
                       float* const wrench[HYDRO_WRENCH_FIELDS], void* stream)
 {
-    if (!h) return HYDRO_E_ARG;
-    float* pv[HYDRO_PREV_FIELDS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (n > 0 && n <= h->capacity && use_device(h->device) == hipSuccess) {
-        int rc = prev_acquire(h, hydro_engine::kPrevSoa, n, static_cast<hipStream_t>(stream));   // (allocates the plain copy on first use)
-        if (rc) return rc;
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = h->prev + f * h->stride;
-    }
+    // everything that can be refused is refused BEFORE the engine's plain-SoA previous velocity is allocated and repacked
+    int rc = check_soa_step(h, n, state, dt, wrench);
+    if (rc || n == 0) return rc;
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    if ((rc = prev_acquire(h, hydro_engine::kPrevSoa, n, static_cast<hipStream_t>(stream)))) return rc;   // (allocates the plain copy on first use)
+    float* pv[HYDRO_PREV_FIELDS];
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = h->prev + f * h->stride;
     return step_soa<true>(h, n, state, pv, pv, dt, wrench, stream);
 }
 
@@ -1726,6 +1797,7 @@ int step_wrench_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t st
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = (uint32_t)n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (own_prev && (rc = prev_acquire(h, hydro_engine::kPrevTiled, n, s))) return rc;
+    if (ke_out && (rc = ke_prepare(h, s))) return rc;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies) : (h->nt != 0);
     const int block = (h->block && !ke_out) ? h->block : 256;               // (the energy partials are one per 256 bodies)
     const dim3 grid(grid_for(n, block)), blk(block);
@@ -1902,6 +1974,7 @@ int step_fused_tiled_impl(hydro_t* h, int64_t n, const float* state, int64_t sta
     a.out = wrench; a.out_stride = wrench ? (uint32_t)wrench_tile_stride : 0;
     a.rho = h->rho; a.g = h->g; a.warp = h->semantics; a.inv_dt = 1.0 / dt; a.n = (uint32_t)n;
     fa.so = state_out; fa.so_stride = (uint32_t)out_tile_stride; fa.dt = (float)dt;
+    if (ke_out && (rc = ke_prepare(h, s))) return rc;
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
 #define HYDRO_FUSED_ARGS a.st, a.pv, a.prm, fa.so, a.out, a.st_stride, a.pv_stride, fa.so_stride, a.out_stride, a.n, a.warp, fa.dt, a.rho, a.g, a.inv_dt, \
@@ -1966,6 +2039,7 @@ int hydro_step_fused_tiled_multi(hydro_t* h, int64_t n, const float* state, int6
     const bool nt = h->nt < 0 ? (n >= kNtMinBodies && !(n >= kFusedTemporalMin && n <= kFusedTemporalMax)) : (h->nt != 0);
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
     const int ke_rot = rotational ? 1 : 0;
+    if (ke_out_dev && (rc = ke_prepare(h, s))) return rc;
 #define HYDRO_MULTI_ARGS state, prev, h->params_tiled, state_out, prev_out, (uint32_t)state_tile_stride, (uint32_t)prev_tile_stride, (uint32_t)out_tile_stride, \
         (uint32_t)prev_out_tile_stride, (uint32_t)n, (uint32_t)steps, dtf, h->rho, h->g, inv_dt, h->ke_partials, h->ke_stride, ke_rot, ke_out_dev
 #define HYDRO_MULTI_W(HALF, NT, KE, WARP) do { if (implicit_drag) hipLaunchKernelGGL((step_fused_multi_tiled_kernel<HALF, NT, true, KE, WARP>), grid, blk, 0, s, HYDRO_MULTI_ARGS); \
@@ -2097,6 +2171,7 @@ static int ke_launch(hydro_engine* h, KeArgs& a, int64_t n, int rotational, doub
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) return ke_of_nothing(h, out_dev, s);
+    if (int rc = ke_prepare(h, s)) return rc;
     const dim3 grid(grid_for(n, kBlock)), blk(kBlock);
     if (rotational) hipLaunchKernelGGL(ke_kernel<true>, grid, blk, 0, s, a);
     else hipLaunchKernelGGL(ke_kernel<false>, grid, blk, 0, s, a);
@@ -2178,56 +2253,116 @@ int hydro_integrate(hydro_t* h, int64_t n, const float* const state_in[HYDRO_STA
     return HYDRO_OK;
 }
 
-// RCCL is bound lazily: a single-GPU user of libhydro.so needs no RCCL at all.  The communicator comes from the caller,
-// so the library to call is the one the caller's process already has (dlsym over the global scope finds it - also the copy
-// a Python host's torch ships); only if there is none the system librccl is opened.  HYDRO_RCCL_LIBRARY names another one.
+// RCCL is bound lazily: a single-GPU user of libhydro.so needs no RCCL at all.  A communicator belongs to ONE copy of the
+// library, so the ncclAllReduce to call is the one of the copy that made the caller's communicator:
+//   1. the address the caller handed over (hydro_bind_rccl: `hydro_bind_rccl((void*)ncclAllReduce)` from C, the symbol of
+//      the library object torch loaded from Python) - no guessing;
+//   2. else HYDRO_RCCL_LIBRARY, if set: that library or nothing;
+//   3. else the copy the process already has (dlsym over the global scope), else the system librccl.
+// Only SUCCESS is latched: a first call before any RCCL is loaded fails with HYDRO_E_STATE and the next one looks again.
 namespace {
 typedef int (*nccl_all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*nccl_error_string_fn)(int);
-nccl_all_reduce_fn g_nccl_all_reduce = nullptr;
+std::mutex g_nccl_mutex;                              // (handles are independent across host threads)
+nccl_all_reduce_fn g_nccl_all_reduce = nullptr;       // written once, under the mutex
 nccl_error_string_fn g_nccl_error_string = nullptr;
-std::once_flag g_nccl_once;                           // (handles are independent across host threads: bind once, whoever comes first)
-constexpr int kNcclFloat64 = 8, kNcclSum = 0;        // rccl.h: ncclDataType_t / ncclRedOp_t
+const char* g_nccl_origin = "unbound";
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;        // rccl.h: ncclDataType_t / ncclRedOp_t (checked below when the header is there)
 
-bool bind_rccl_once()
+nccl_all_reduce_fn lookup_rccl(nccl_error_string_fn* err_fn, const char** origin)
 {
     void* lib = nullptr;
     const char* named = getenv("HYDRO_RCCL_LIBRARY");
     void* sym = named ? nullptr : dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    *origin = "the copy already loaded in the process";
     if (!sym) {
         const char* candidates[] = {named, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* c : candidates) {
             if (!c) continue;
-            if ((lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL))) break;
-            if (c == named) return false;             // the one that was asked for, or nothing
+            if ((lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL))) { *origin = (c == named) ? "HYDRO_RCCL_LIBRARY" : "librccl opened by libhydro"; break; }
+            if (c == named) return nullptr;           // the one that was asked for, or nothing
         }
-        if (!lib) return false;
+        if (!lib) return nullptr;
         sym = dlsym(lib, "ncclAllReduce");
     }
-    g_nccl_error_string = reinterpret_cast<nccl_error_string_fn>(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
-    g_nccl_all_reduce = reinterpret_cast<nccl_all_reduce_fn>(sym);
-    return g_nccl_all_reduce != nullptr;
+    *err_fn = reinterpret_cast<nccl_error_string_fn>(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    return reinterpret_cast<nccl_all_reduce_fn>(sym);
 }
 
-bool bind_rccl()
+nccl_all_reduce_fn bound_rccl()
 {
-    std::call_once(g_nccl_once, [] { (void)bind_rccl_once(); });
-    return g_nccl_all_reduce != nullptr;
+    std::lock_guard<std::mutex> lock(g_nccl_mutex);
+    if (!g_nccl_all_reduce) {
+        nccl_error_string_fn err_fn = nullptr;
+        const char* origin = "unbound";
+        if (nccl_all_reduce_fn fn = lookup_rccl(&err_fn, &origin)) { g_nccl_error_string = err_fn; g_nccl_origin = origin; g_nccl_all_reduce = fn; }
+    }
+    return g_nccl_all_reduce;
 }
 }  // namespace
+
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+}  // extern "C"
+#include <rccl/rccl.h>
+static_assert((int)ncclFloat64 == kNcclFloat64 && (int)ncclSum == kNcclSum, "rccl.h moved ncclFloat64 / ncclSum");
+extern "C" {
+#endif
+#endif
+
+int hydro_bind_rccl(void* nccl_all_reduce, void* nccl_get_error_string)
+{
+    std::lock_guard<std::mutex> lock(g_nccl_mutex);
+    if (!nccl_all_reduce) {                            // forget: the next hydro_ke_allreduce looks the library up again
+        g_nccl_all_reduce = nullptr; g_nccl_error_string = nullptr; g_nccl_origin = "unbound";
+        return HYDRO_OK;
+    }
+    g_nccl_all_reduce = reinterpret_cast<nccl_all_reduce_fn>(nccl_all_reduce);
+    g_nccl_error_string = reinterpret_cast<nccl_error_string_fn>(nccl_get_error_string);
+    g_nccl_origin = "hydro_bind_rccl";
+    return HYDRO_OK;
+}
+
+const char* hydro_rccl_origin(void)
+{
+    std::lock_guard<std::mutex> lock(g_nccl_mutex);
+    return g_nccl_origin;
+}
 
 int hydro_ke_allreduce(hydro_t* h, void* nccl_comm, double* ke_dev, void* stream)
 {
     if (!h) return HYDRO_E_ARG;
     if (!nccl_comm || !ke_dev) return fail(h, HYDRO_E_ARG, "null communicator or buffer");
-    if (!bind_rccl()) return fail(h, HYDRO_E_STATE, "RCCL is not available in this process (no ncclAllReduce loaded, librccl.so not found; HYDRO_RCCL_LIBRARY names one)");
+    const nccl_all_reduce_fn all_reduce = bound_rccl();
+    if (!all_reduce) return fail(h, HYDRO_E_STATE, "RCCL is not available in this process (no ncclAllReduce loaded, librccl.so not found; hydro_bind_rccl hands one over, HYDRO_RCCL_LIBRARY names one)");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     // in place, two doubles: [translational, rotational] (ncclAllReduce(count = 1..2, ncclDouble, ncclSum))
-    const int rc = g_nccl_all_reduce(ke_dev, ke_dev, 2, kNcclFloat64, kNcclSum, nccl_comm, static_cast<hipStream_t>(stream));
+    const int rc = all_reduce(ke_dev, ke_dev, 2, kNcclFloat64, kNcclSum, nccl_comm, static_cast<hipStream_t>(stream));
     if (rc != 0) {
         snprintf(h->err, sizeof h->err, "ncclAllReduce: %s", g_nccl_error_string ? g_nccl_error_string(rc) : "failed");
         return HYDRO_E_LAUNCH;
     }
+    return HYDRO_OK;
+}
+
+int hydro_ke_rearm(hydro_t* h, void* stream)
+{
+    if (!h) return HYDRO_E_ARG;
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, hipMemsetAsync(ke_counters(h), 0, kKeCounterBytes, static_cast<hipStream_t>(stream)), HYDRO_E_LAUNCH);
+    h->ke_suspect = false;
+    return HYDRO_OK;
+}
+
+int hydro_debug_ke_fault(hydro_t* h, int counter, uint32_t value, int as_failed_launch)
+{
+    if (!h) return HYDRO_E_ARG;
+    if (counter < 0 || counter > (int)kKeClasses) return fail(h, HYDRO_E_ARG, "counter must be 0 (top) .. 64 (class 63)");
+    HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
+    HYDRO_HIP(h, hipDeviceSynchronize(), HYDRO_E_LAUNCH);
+    if (hipMemcpy(ke_counters(h) + 64 * counter, &value, sizeof value, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(h, HYDRO_E_LAUNCH, "hydro_debug_ke_fault: copy failed");
+    if (as_failed_launch) h->ke_suspect = true;        // what fail() does when a HIP call of this handle reports an error
     return HYDRO_OK;
 }
 
@@ -2239,12 +2374,12 @@ int hydro_set_semantics(hydro_t* h, int semantics)
     if (semantics == HYDRO_SEM_WARP) {
         // said once per process: this mode restates warp_hydrodynamics.py from its source text; the reference holds no
         // outputs of its Warp calculator and `warp` cannot be imported where this library is built - PARITY UNPINNED
-        static bool told = false;
-        if (!told && !getenv("HYDRO_QUIET")) {
-            told = true;
-            fprintf(stderr, "[libhydro] HYDRO_SEM_WARP: restated from the source text of warp_hydrodynamics.py, no reference "
-                            "outputs behind it (parity unpinned); HYDRO_SEM_NUMBA is the verified mode\n");
-        }
+        static std::once_flag told;               // (handles are independent across host threads)
+        if (!getenv("HYDRO_QUIET"))
+            std::call_once(told, [] {
+                fprintf(stderr, "[libhydro] HYDRO_SEM_WARP: restated from the source text of warp_hydrodynamics.py, no reference "
+                                "outputs behind it (parity unpinned); HYDRO_SEM_NUMBA is the verified mode\n");
+            });
     }
     h->semantics = semantics;
     return HYDRO_OK;

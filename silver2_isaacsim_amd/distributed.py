@@ -91,6 +91,32 @@ def all_reduce_max_(t: torch.Tensor):
     return t
 
 
+def live_ranks(device: torch.device | str = "cpu") -> int:
+    """How many ranks the LIVE process group really joins in a collective: every rank contributes a 1 to a SUM
+    all-reduce (RCCL under backend "nccl").  1 without a group.  A launcher that started fewer ranks than the
+    benchmark was asked for shows up here, whatever the environment variables say."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    one = torch.ones(1, dtype=torch.int64, device=collective_device(device))
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def gather_rows(row, device: torch.device | str = "cpu", dtype=torch.float64) -> torch.Tensor:
+    """(world, k) tensor on the CPU whose row r is rank r's `row` (k numbers, the same k on every rank).  A SUM
+    all-reduce in which every rank fills only its own row of zeros: x + 0 is exact, so nothing of the result depends
+    on the order the ranks are added in - a gather built from the one collective the path needs anyway."""
+    vals = torch.as_tensor(row, dtype=dtype).reshape(-1).cpu()
+    if not _collectives_on():
+        return vals.reshape(1, -1)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros((world, vals.numel()), dtype=dtype)
+    t[rank] = vals
+    t = t.to(collective_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu()
+
+
 def global_kinetic_energy(local_ke: torch.Tensor, async_op: bool = False):
     """All-reduce the per-rank kinetic-energy scalar(s) (float64, shape (1,) or (2,)
     = [translational, rotational]).  `local_ke` lives on the rank's device for

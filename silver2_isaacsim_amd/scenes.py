@@ -18,6 +18,7 @@ hydrodynamics_behavior.py:30-45.
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -296,6 +297,23 @@ SCENES = {"c1": scene_c1, "c2": scene_c2, "c3": scene_c3, "c4": scene_c4, "c5": 
 
 def make_scene(name: str, **kw) -> Scene:
     return SCENES[name.lower()](**kw)
+
+
+def kinetic_energy_fp64(state: np.ndarray, params: np.ndarray, rotational: bool = True) -> tuple[float, float]:
+    """[translational, rotational] kinetic energy of a scene as a float64 host sum: sum 1/2 m |v|^2 and
+    sum 1/2 w_b^T diag(m/12 (d^2+h^2), m/12 (w^2+h^2), m/12 (w^2+d^2)) w_b with w_b = R^T w (the quaternion used as given,
+    SURVEY.md 8e).  The quantity does not exist in the reference; this sum is what the device reduction and the
+    all-reduce over the ranks are checked against (bench.py `rel_err_vs_host_fp64`, tests)."""
+    st = np.asarray(state, dtype=np.float64)
+    pr = np.asarray(params, dtype=np.float64)
+    m = pr[:, 10]
+    lin = math.fsum(0.5 * m * (st[:, 7:10] ** 2).sum(axis=1))
+    if not rotational:
+        return lin, 0.0
+    wb = np.einsum("nba,nb->na", _rot(st[:, 3:7]), st[:, 10:13])
+    d2 = pr[:, 0:3] ** 2
+    inertia = (m / 12.0)[:, None] * np.stack([d2[:, 1] + d2[:, 2], d2[:, 0] + d2[:, 2], d2[:, 0] + d2[:, 1]], axis=1)
+    return lin, math.fsum(0.5 * (inertia * wb * wb).sum(axis=1))
 
 
 def to_soa(arr: np.ndarray) -> np.ndarray:

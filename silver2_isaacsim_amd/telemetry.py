@@ -16,6 +16,7 @@ import datetime
 import logging
 import os
 import time
+from dataclasses import dataclass
 from typing import Callable
 
 log = logging.getLogger("silver2_isaacsim_amd")
@@ -28,77 +29,88 @@ CSV_HEADER = ["timestamp",                               # log_velocity.py:17-20
               "y_position", "linear_velocity_y", "angular_velocity_y"]
 
 
+# The artefact IS the text (SURVEY.md 8f row 3 asks for the reference's RTF printer): every line the meter can emit, in one
+# table, so that tests/test_telemetry.py pins the format and the class below holds no format strings of its own.
+RTF_LINES = {
+    "ready": "[RTF Benchmark] Initialized. Ready to run.",
+    "live": "[RTF Live] Sim: {sim:.2f}s | RTF: {rtf:.3f}",
+    "report": ("\n" + "=" * 40,
+               "BENCHMARK RESULTS",
+               "-" * 40,
+               "Total Wall Time:  {wall_time_s:.4f} s",
+               "Total Sim Time:   {sim_time_s:.4f} s",
+               "Physics Steps:    {physics_steps}",
+               "-" * 40,
+               "AVERAGE RTF:      {rtf:.4f} x",
+               "AVERAGE FPS:      {fps:.2f}",
+               "=" * 40 + "\n"),
+}
+MIN_WALL_S = 0.001                                       # shorter runs report nothing (benchmark_rtf.py:55-57)
+
+
+@dataclass
+class RtfRun:
+    """One play -> stop interval of the meter."""
+    started: float                                       # wall clock at play
+    sim_time: float = 0.0                                # sum of the physics dt handed to the step callback
+    steps: int = 0
+
+    def summary(self, now: float) -> dict | None:
+        wall = now - self.started
+        if wall < MIN_WALL_S:
+            return None
+        return {"wall_time_s": wall, "sim_time_s": self.sim_time, "physics_steps": self.steps,
+                "rtf": self.sim_time / wall, "fps": self.steps / wall}
+
+
 class BenchmarkRtf:
-    """Standalone real-time-factor meter (whole-simulator metric, not a kernel benchmark)."""
+    """Standalone real-time-factor meter (whole-simulator metric, not a kernel benchmark): RTF = simulated time / wall
+    time between play and stop, a live line every 600 physics steps, a final block at stop.  `clock` and `out` are
+    injectable (tests; a host that wants the lines in its own log)."""
 
     def __init__(self, host=None, clock: Callable[[], float] = time.time, out: Callable[[str], None] = print):
-        self._host = host
-        self._clock = clock
-        self._out = out
-        self._physx_subscription = None
-        self._running = False
+        self._host, self._clock, self._out = host, clock, out
+        self._token = None                               # the physics-step subscription while playing
+        self.run: RtfRun | None = None                   # the current (or last) interval
+        self._live = False
 
+    # lifecycle, as Kit calls a behavior script
     def on_init(self):
-        self._physx_subscription = None
-        self._running = False
-        self._out("[RTF Benchmark] Initialized. Ready to run.")
+        self._token, self._live = None, False
+        self._out(RTF_LINES["ready"])
 
     def on_destroy(self):
-        self._physx_subscription = None
+        self._token = None
 
     def on_play(self):
-        self._start_wall_time = self._clock()
-        self._total_sim_time = 0.0
-        self._frame_count = 0
-        self._running = True
+        self.run = RtfRun(started=self._clock())
+        self._live = True
         if self._host is not None:
-            self._physx_subscription = self._host.subscribe_physics_step(self._on_physics_step)
+            self._token = self._host.subscribe_physics_step(self._on_physics_step)
         log.info("[RTF Benchmark] Benchmarking started...")
 
     def on_stop(self):
-        stats = self._report_final_stats()
-        self._running = False
-        self._physx_subscription = None
-        return stats
+        summary = self.stats()
+        if summary is not None:
+            for line in RTF_LINES["report"]:
+                self._out(line.format(**summary))
+        self._live, self._token = False, None
+        return summary
 
     def _on_physics_step(self, delta_time: float):
-        if not self._running:
+        run = self.run
+        if not self._live or run is None:
             return
-        self._total_sim_time += delta_time
-        self._frame_count += 1
-        if self._frame_count % LIVE_EVERY_STEPS == 0:
-            self._print_live_stats()
+        run.sim_time += delta_time
+        run.steps += 1
+        if run.steps % LIVE_EVERY_STEPS == 0:
+            wall = self._clock() - run.started
+            self._out(RTF_LINES["live"].format(sim=run.sim_time, rtf=run.sim_time / wall if wall > 0 else float("inf")))
 
     def stats(self) -> dict | None:
-        if not hasattr(self, "_start_wall_time"):
-            return None
-        wall = self._clock() - self._start_wall_time
-        if wall < 0.001:                                 # benchmark_rtf.py:55-57
-            return None
-        return {"wall_time_s": wall, "sim_time_s": self._total_sim_time, "physics_steps": self._frame_count,
-                "rtf": self._total_sim_time / wall, "fps": self._frame_count / wall}
-
-    def _report_final_stats(self):
-        s = self.stats()
-        if s is None:
-            return None
-        bar, rule = "=" * 40, "-" * 40
-        self._out(f"\n{bar}")
-        self._out("BENCHMARK RESULTS")
-        self._out(rule)
-        self._out(f"Total Wall Time:  {s['wall_time_s']:.4f} s")
-        self._out(f"Total Sim Time:   {s['sim_time_s']:.4f} s")
-        self._out(f"Physics Steps:    {s['physics_steps']}")
-        self._out(rule)
-        self._out(f"AVERAGE RTF:      {s['rtf']:.4f} x")
-        self._out(f"AVERAGE FPS:      {s['fps']:.2f}")
-        self._out(f"{bar}\n")
-        return s
-
-    def _print_live_stats(self):
-        current_wall = self._clock() - self._start_wall_time
-        rtf = self._total_sim_time / current_wall if current_wall > 0 else float("inf")
-        self._out(f"[RTF Live] Sim: {self._total_sim_time:.2f}s | RTF: {rtf:.3f}")
+        """{"wall_time_s", "sim_time_s", "physics_steps", "rtf", "fps"} of the current interval; None before the first play
+        and for intervals shorter than a millisecond."""
+        return None if self.run is None else self.run.summary(self._clock())
 
 
 class LogVelocity:

@@ -70,8 +70,11 @@ class FakeRigidView:
         """buffers: what `get_world_poses / get_velocities(clone=False)` hand out -
         "stable" the same device tensors every step (a tensor API's views; the best case for the plugin's prepared
         launch), "fresh" newly allocated tensors every step, "strided" non-contiguous views of wider tensors,
-        "numpy" host NumPy arrays (a view created without the torch backend, hydrodynamics_behavior.py:50-51)."""
-        if buffers not in ("stable", "fresh", "strided", "numpy"):
+        "numpy" host NumPy arrays (a view created without the torch backend, hydrodynamics_behavior.py:50-51),
+        "static" the same device tensors every step, filled ONCE at initialize() and never refreshed, and an apply that only
+        counts: a view that costs the host nothing, so that what is left of a physics step is the plugin's own work
+        (bench.py `plugin_own_us_per_step`)."""
+        if buffers not in ("stable", "fresh", "strided", "numpy", "static"):
             raise ValueError(buffers)
         self.buffers = buffers
         self.world, self.name = world, name
@@ -87,6 +90,10 @@ class FakeRigidView:
 
     def initialize(self):
         self._ok = True
+        if self.buffers == "static":
+            torch.index_select(self.world.positions, 0, self.idx, out=self._pos)
+            torch.index_select(self.world.orientations, 0, self.idx, out=self._quat)
+            torch.index_select(self.world.velocities, 0, self.idx, out=self._vel)
 
     def is_valid(self):
         return self._ok
@@ -95,6 +102,8 @@ class FakeRigidView:
         if self.fail_next_fetch:
             self.fail_next_fetch = False
             raise RuntimeError("simulated tensor API failure")
+        if self.buffers == "static":
+            return self._pos, self._quat
         torch.index_select(self.world.positions, 0, self.idx, out=self._pos)
         torch.index_select(self.world.orientations, 0, self.idx, out=self._quat)
         if clone or self.buffers != "stable":
@@ -102,6 +111,8 @@ class FakeRigidView:
         return self._pos, self._quat
 
     def get_velocities(self, clone=False):
+        if self.buffers == "static":
+            return self._vel
         torch.index_select(self.world.velocities, 0, self.idx, out=self._vel)
         return self._hand_out(self._vel) if clone or self.buffers != "stable" else self._vel
 
@@ -120,6 +131,8 @@ class FakeRigidView:
 
     def apply_forces_and_torques_at_pos(self, forces=None, torques=None, positions=None, is_global=True):
         self.world.apply_calls += 1
+        if self.buffers == "static":
+            return
         if self._force is None or self._force.shape != forces.shape:
             self._force, self._torque = torch.empty_like(forces), torch.empty_like(torques)
             for k, p in enumerate(self.paths):

@@ -139,3 +139,27 @@ def test_kit_host_follows_the_reference_rule_for_a_missing_json(tmp_path, caplog
     (empty / cfg.CONFIG_FILE_NAME).write_text(json.dumps(edited))
     for h in (KitHost(config_dir=str(empty)), KitHost(config_dir=str(empty), use_builtin_table=True)):
         assert cfg.load_config(h.config_path())["globals"]["waterDensity"] == 999.0      # a user's JSON always wins
+
+
+def test_default_kit_host_applies_the_shipped_table_like_the_reference(tmp_path):
+    """The reference ships hydrodynamics_config.json beside hydrodynamics_behavior.py and applies it at on_init (:72-112).
+    A default drop-in - KitHost() with no config_dir - must run with the same parameters out of the box: it resolves to
+    the table the package carries as constants (config.default_config() = hydrodynamics_config.json:2-54).  A host that
+    names a directory keeps the literal rule for a missing file (warning, USD values stay)."""
+    import json
+    import os
+    from silver2_isaacsim_amd import config as cfg
+    from silver2_isaacsim_amd.behavior import KitHost
+    data = cfg.load_config(KitHost().config_path())
+    assert data == cfg.default_config()
+    assert list(data["parts"]) == ["body", "coxa", "femur", "tibia"]          # key order is the match order (:91-101)
+    tib = cfg.resolve_overrides("Tibia_3", data)                              # what a SILVER2 tibia gets out of the box
+    assert tib["linearDamping"] == 20.0 and tib["yDimension"] == 0.09 and tib["waterDensity"] == 1025.0
+    assert "xDimension" not in cfg.resolve_overrides("Obsea_Buoy", data)       # no part matches: USD values stay, globals applied
+    # explicit directory without a JSON: the reference's rule; explicit opt-out for the default directory too
+    assert KitHost(config_dir=str(tmp_path)).config_path() == str(tmp_path / cfg.CONFIG_FILE_NAME)
+    assert KitHost(use_builtin_table=False).config_path().endswith(cfg.CONFIG_FILE_NAME)
+    # a JSON dropped beside the package wins over the constants (a user's file always does)
+    ref = "/root/reference/src/scripts/physics/hydrodynamics_config.json"
+    if os.path.exists(ref):                                                   # (the build container only: the reference never travels)
+        assert json.load(open(ref)) == data

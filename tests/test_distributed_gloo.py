@@ -41,6 +41,17 @@ def _worker(rank, world, port, q, barrier_kind="node"):
     work.wait()
     mt = sc.params[:, 10].astype(np.float64)
     ke_full = float((0.5 * mt * (sc.state[:, 7:10].astype(np.float64) ** 2).sum(1)).sum())
+    # what bench.py's N > 1 line proves itself with: the ranks that really join an all-reduce, an exact gather of per-rank
+    # rows (digests of the shard wrenches, host sums), the float64 host sum of the kinetic energy
+    assert hd.live_ranks() == world
+    rows = hd.gather_rows([rank + 0.1, -rank, 1e300 * (rank + 1)])
+    assert rows.shape == (world, 3) and rows.tolist() == [[r + 0.1, -r, 1e300 * (r + 1)] for r in range(world)]
+    dig = hd.gather_rows(list(range(rank, rank + 32)), dtype=torch.int64)
+    assert dig.dtype == torch.int64 and dig.tolist() == [list(range(r, r + 32)) for r in range(world)]
+    lin_full, rot_full = scenes.kinetic_energy_fp64(sc.state, sc.params)
+    parts = hd.gather_rows(scenes.kinetic_energy_fp64(mine.state, mine.params))
+    assert float(parts[:, 0].sum()) == pytest.approx(lin_full, rel=1e-14) and float(parts[:, 1].sum()) == pytest.approx(rot_full, rel=1e-14)
+    assert lin_full == pytest.approx(ke_full, rel=1e-14) and rot_full > 0
     # max-over-ranks timing used by bench.py
     tm = torch.tensor([1.0 + rank], dtype=torch.float64)
     hd.all_reduce_max_(tm)

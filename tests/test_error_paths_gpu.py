@@ -138,3 +138,98 @@ def test_array_of_structs_and_layout_errors(rig):
     _expect_arg(eng, L.hydro_kinetic_energy_tiled(h, N, p(state), ST - 64, 0, p(torch.zeros(2, dtype=torch.float64, device=DEV)), None), "tile stride")
     torch.cuda.synchronize()
     assert not tiled_state.any() and (f == 7.0).all()
+
+
+# ---- the kinetic-energy reduction after a launch that did not finish -----------------------
+def _ke_rig(n=100003, seed=31):
+    sc = scenes.scene_c4(n=n, seed=seed)
+    eng = HydroEngine(sc.n, DEV, sc.rho, sc.g)
+    eng.set_params(sc.params)
+    st = torch.from_numpy(scenes.to_tiled(sc.state)).to(DEV)
+    return sc, eng, st
+
+
+def test_kinetic_energy_never_returns_a_stale_pair_and_rearms():
+    """The reduction's ticket counters are zero between launches that finish.  A launch that was cut short (device reset,
+    aborted graph) leaves some of them non-zero, and no later launch then draws the "last" ticket.  hydro_debug_ke_fault puts
+    a counter into that state.  What must hold: (1) the next result is NaN - block 0 poisons the output before any ticket
+    is drawn - never the pair of an earlier launch; (2) hydro_ke_rearm restores the reduction, same bits as before;
+    (3) a fault that the library has SEEN (a failed HIP call marks the handle) is repaired by the next launch itself."""
+    sc, eng, st = _ke_rig()
+    L, h = eng._lib, eng._h
+    good = eng.kinetic_energy(st, rotational=True).clone()
+    lin, rot = scenes.kinetic_energy_fp64(sc.state, sc.params)
+    assert good[0].item() == pytest.approx(lin, rel=1e-12) and good[1].item() == pytest.approx(rot, rel=1e-12)
+    out = good.clone()                                                # holds a perfectly plausible pair from an earlier launch
+    # (1) the top counter at 64: the class finishers draw 64 .. 127, none of them the last ticket (63) - no final sum
+    assert L.hydro_debug_ke_fault(h, 0, 64, 0) == 0
+    eng.kinetic_energy(st, rotational=True, out=out)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()                                     # visible, not stale
+    # (2) the documented recovery
+    eng.ke_rearm()
+    eng.kinetic_energy(st, rotational=True, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, good)
+    assert torch.equal(eng.kinetic_energy(st, rotational=True), good)     # and the launch left the counters at zero again
+    # (3) class counter 5 left at 3 by a launch the library saw fail: the next launch zeroes the counters first
+    assert L.hydro_debug_ke_fault(h, 1 + 5, 3, 1) == 0
+    eng.kinetic_energy(st, rotational=True, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, good)
+    # the same through the sampling step kernels (they share the scratch and the counters)
+    prev = torch.from_numpy(scenes.to_tiled(sc.prev)).to(DEV)
+    ke = torch.zeros(2, dtype=torch.float64, device=DEV)
+    assert L.hydro_debug_ke_fault(h, 0, 64, 0) == 0
+    eng.step_wrench_tiled(st, sc.n, sc.dt, prev=prev, ke_out=ke, rotational=True)
+    torch.cuda.synchronize()
+    assert torch.isnan(ke).all()
+    assert L.hydro_debug_ke_fault(h, 0, 64, 1) == 0                   # (seen by the library this time)
+    eng.step_wrench_tiled(st, sc.n, sc.dt, prev=prev, ke_out=ke, rotational=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ke, good)
+    assert L.hydro_debug_ke_fault(h, 65, 1, 0) == E_ARG and L.hydro_debug_ke_fault(h, -1, 1, 0) == E_ARG
+    eng.close()
+
+
+def test_kinetic_energy_launches_on_two_streams_are_ordered_by_the_library():
+    """Two reductions of one engine in flight at once would draw each other's tickets.  The library orders a launch on a
+    stream other than the previous one's behind it (an event wait on the device): alternating two streams without any
+    synchronisation by the caller gives the bits of the single-stream result every time."""
+    sc, eng, st = _ke_rig(n=1048576 // 4, seed=32)
+    good = eng.kinetic_energy(st, rotational=True).clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    outs = [torch.zeros(2, dtype=torch.float64, device=DEV) for _ in range(40)]
+    for k, o in enumerate(outs):
+        eng.kinetic_energy(st, rotational=True, out=o, stream=streams[k % 2])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, good)
+    eng.close()
+
+
+def test_plain_soa_step_validates_before_it_allocates():
+    """hydro_step_wrench keeps the previous velocity in an engine-owned plain-SoA copy that is allocated on first use:
+    a call that is going to be refused must be refused BEFORE that (n beyond the parameters, bad dt, null tables)."""
+    sc = scenes.scene_c4(n=4096, seed=33)
+    eng = HydroEngine(1 << 20, DEV, sc.rho, sc.g)                     # 82 B per body of plain-SoA copies = 86 MB if they came
+    eng.set_params(sc.params)
+    L, h = eng._lib, eng._h
+    S = torch.from_numpy(scenes.to_soa(sc.state)).to(DEV)
+    W = torch.empty((6, sc.n), device=DEV)
+    tab_s, tab_w = eng._table(S, 13), eng._table(W, 6)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(DEV)[0]
+    assert L.hydro_step_wrench(h, sc.n + 1, tab_s, sc.dt, tab_w, None) == -5          # HYDRO_E_STATE: parameters not set for n bodies
+    assert L.hydro_step_wrench(h, sc.n, tab_s, 0.0, tab_w, None) == E_ARG
+    assert L.hydro_step_wrench(h, sc.n, None, sc.dt, tab_w, None) == E_ARG
+    assert L.hydro_step_wrench(h, (1 << 20) + 1, tab_s, sc.dt, tab_w, None) == E_ARG
+    holes = nat.pointer_table([S[f].data_ptr() if f != 4 else 0 for f in range(13)])
+    assert L.hydro_step_wrench(h, sc.n, holes, sc.dt, tab_w, None) == E_ARG
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(DEV)[0] == free0                   # nothing was allocated by any of them
+    assert L.hydro_step_wrench(h, sc.n, tab_s, sc.dt, tab_w, None) == 0              # the good call does allocate, once
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(DEV)[0] < free0 and torch.isfinite(W).all()
+    eng.close()

@@ -90,3 +90,67 @@ def test_committed_instruction_mix_is_current(assembly):
     assert committed == isa_mix.mix(assembly), "run `python scripts/isa_mix.py` and commit profiles/isa_mix.json"
     loop = next(v for k, v in committed.items() if k.startswith("resident closed loop, one step ("))
     assert loop["valu_total"] <= 530                          # the per-step loop of the resident kernel (round 3: 527 + 3)
+
+
+# ---- the kinetic-energy reduction's memory protocol (hydro_kernels.hip "kinetic-energy reduction") -------------------------
+# Relaxed device-scope atomics + s_waitcnt stand in for release / acquire (a release fence is a buffer_wbl2: 30 us per launch
+# at 1 M bodies).  That is only correct while the compiler keeps THIS order, so the order is pinned here, per kernel that
+# carries the reduction: a compiler bump that sinks a published value below its ticket fails the CPU suite.
+KE_KERNELS = {
+    "stand-alone, rotational": "ke_kernelILb1E",
+    "stand-alone, translational": "ke_kernelILb0E",
+    "tiled wrench, sampling <256, f32, caller prev, streaming, KE, Numba>": "wrench_tiled_kernelILi256ELb0ELb0ELb1ELb1ELb0E",
+    "tiled wrench, sampling <256, f16, engine prev, temporal, KE, Numba>": "wrench_tiled_kernelILi256ELb1ELb1ELb0ELb1ELb0E",
+    "fused step, sampling <f32, streaming, explicit, KE, Numba>": "step_fused_tiled_kernelILb0ELb1ELb0ELb1ELb0E",
+    "resident multi-step, sampling <f32, temporal, explicit, KE, Numba>": "step_fused_multi_tiled_kernelILb0ELb0ELb0ELb1ELb0E",
+}
+
+
+def _protocol_events(body):
+    """The instructions the protocol is made of, in program order: ('publish' | 'wait' | 'ticket' | 'inv' | 'fetch' | ...)."""
+    ev = []
+    for line in body.splitlines():
+        l = line.strip()
+        if re.match(r"global_store_dwordx2 .* sc1$", l):
+            ev.append("publish")                                     # write-through fp64 store (partial, class sum, poison, result)
+        elif re.match(r"global_store_dword .* sc1$", l):
+            ev.append("reset")                                       # a finisher zeroes its counter
+        elif l.startswith("global_atomic_add"):
+            ev.append("ticket")
+        elif l.startswith("s_waitcnt") and "vmcnt(0)" in l:
+            ev.append("wait")
+        elif l.startswith("buffer_inv"):
+            assert l == "buffer_inv sc1", l
+            ev.append("inv")
+        elif re.match(r"global_load_dwordx2 .* sc1$", l):
+            ev.append("fetch")
+        elif l.startswith(("buffer_wbl2", "global_wb", "buffer_gl")):
+            ev.append("writeback:" + l)
+        elif l.startswith("global_atomic"):
+            ev.append("other-atomic:" + l)
+    return ev
+
+
+@pytest.mark.parametrize("which", sorted(KE_KERNELS))
+def test_kinetic_energy_reduction_keeps_its_memory_order(assembly, which):
+    body = _body(assembly, KE_KERNELS[which])
+    ev = _protocol_events(body)
+    assert not [e for e in ev if e.startswith(("writeback", "other-atomic"))], ev      # no L2 write-back fence, integer tickets only
+    assert "v_mfma" not in body
+    tickets = [i for i, e in enumerate(ev) if e == "ticket"]
+    assert len(tickets) == 2, ev                                     # the class counter, then the top counter
+    for t in tickets:
+        # producer side: published values -> s_waitcnt vmcnt(0) -> the ticket, nothing published in between
+        before = ev[:t]
+        assert before[-1] == "wait", (which, before[-4:])
+        assert "publish" in before[:-1] and before[:-1][-1] in ("publish", "reset"), (which, before[-4:])
+        # consumer side: the ticket's value is waited for, then the non-coherent caches are invalidated, THEN others' values are read
+        after = ev[t + 1:]
+        assert after[0] == "wait" and after[1] == "inv", (which, after[:4])
+        nxt = [e for e in after[2:] if e != "wait"]
+        assert nxt and nxt[0] == "fetch", (which, after[:6])
+    # no value of another block is fetched before the first ticket has been drawn and its invalidate issued
+    assert "fetch" not in ev[:tickets[0] + 3]
+    # the poison of `out` (block 0) precedes the first ticket, the result is the last thing published (then the top counter is zeroed)
+    assert ev[:tickets[0]].count("publish") == 4                     # block 0's two NaNs, then the block's pair
+    assert ev[-3:] == ["publish", "publish", "reset"], ev[-5:]

@@ -60,21 +60,31 @@ def test_monitor_all_reduce_goes_through_rccl(native_built):
     assert d["ke"] == pytest.approx(d["want"], rel=1e-12)
 
 
-def test_bench_strong_leg_over_rccl(native_built):
-    """bench.py's N > 1 path (weak headline + c4_strong leg + monitor) with the nccl backend and one rank: WORLD_SIZE=1
-    normally means "no process group", HYDRO_BENCH_FORCE_GROUP=1 makes the bench build a one-rank RCCL group and take
-    the multi-rank code path."""
+def _bench_over_rccl(steps, warmup):
     import json
     env = dict(os.environ, HYDRO_DIST_ALWAYS="1", HYDRO_BENCH_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "600", "--warmup", "8", "--bodies", "65536",
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--bodies", "65536",
            "--spinup-seconds", "0.1", "--cpu-seconds", "0", "--no-extras"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
-    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("steps,warmup,every,samples", [(20, 5, 10, 2), (600, 8, 256, 2)])
+def test_bench_strong_leg_over_rccl(native_built, steps, warmup, every, samples):
+    """bench.py's N > 1 path (weak headline + c4_strong leg + monitor) with the nccl backend and one rank: WORLD_SIZE=1
+    normally means "no process group", HYDRO_BENCH_FORCE_GROUP=1 makes the bench build a one-rank RCCL group and take
+    the multi-rank code path - at the driver's own `--steps 20 --warmup 5` and at a long region.  The asynchronous
+    all-reduce on the side stream runs at least twice inside the timed region and the leg's self-checks hold."""
+    d = _bench_over_rccl(steps, warmup)
     cs = d["c4_strong"]
-    assert cs["bodies_this_rank"] == 262144 and cs["kinetic_energy"]["samples"] == 2 and cs["kinetic_energy"]["host_waits"] == 0
-    assert d["collectives"] == "nccl (RCCL), 1 rank(s)"
+    ke = cs["kinetic_energy"]
+    assert cs["bodies_this_rank"] == 262144 and ke["every_steps"] == every and ke["samples"] == samples and ke["samples"] >= 2
+    assert ke["host_waits"] == 0 or steps == 20        # (a 20-step region is over before the first sample has landed: collect(block=True) waits once or twice)
+    assert ke["rel_err_vs_host_fp64"] <= 1e-12 and cs["shards_bit_identical"] is True
+    assert d["global_kinetic_energy_rel_err_vs_host_fp64"] <= 1e-12
+    assert d["collectives"] == "nccl (RCCL), 1 rank(s)" and d["rccl_ranks"] == 1 and d["collective_ranks"] == 1
     assert d["barrier"] == "node-local shared-memory epoch barrier"      # built over the RCCL group's own collectives
 
 

@@ -31,8 +31,11 @@ def test_rtf_meter_counts_sim_time_and_reports():
     for needle in ("BENCHMARK RESULTS", "Total Wall Time:  10.0000 s", "Total Sim Time:   20.0000 s",
                    "Physics Steps:    1200", "AVERAGE RTF:      2.0000 x", "AVERAGE FPS:      120.00"):
         assert needle in text
+    # the final block, line for line (the printed artefact of benchmark_rtf.py:59-71)
+    assert lines[-10:] == ["\n" + "=" * 40, "BENCHMARK RESULTS", "-" * 40, "Total Wall Time:  10.0000 s", "Total Sim Time:   20.0000 s",
+                           "Physics Steps:    1200", "-" * 40, "AVERAGE RTF:      2.0000 x", "AVERAGE FPS:      120.00", "=" * 40 + "\n"]
     host.step(1 / 60)                              # stopped: ignored
-    assert rtf._frame_count == 1200
+    assert rtf.run.steps == 1200 and rtf.stats()["physics_steps"] == 1200
     assert BenchmarkRtf(host).on_stop() is None    # never played: no report
 
 
