@@ -187,12 +187,13 @@ def timed_steps(replicas, steps: int, warmup: int, stream, collectives: bool = F
     dev = replicas[0].state.device
     grouped = hd._collectives_on()
     with torch.cuda.stream(stream):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream); ev1.record(stream)              # (a torch event is created by its first record: not inside the region)
         for k in range(warmup):
             replicas[k % len(replicas)].step()
         torch.cuda.synchronize(dev)
         hd.barrier()
         torch.cuda.synchronize(dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
         for k in range(steps):
@@ -394,7 +395,7 @@ def graph_rate(kind: str, n: int, coeff: str, dev, stream, steps_per_graph: int 
         for k in range(8):
             reps[k % 4].step()
         stream.synchronize()
-        with torch.cuda.graph(g, stream=stream):
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             for k in range(steps_per_graph):
                 reps[k % 4].step()
         for _ in range(5):
@@ -606,7 +607,7 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
         reps[1].step_sampling(ke_dev)                                 # (prepare outside the capture)
         reps[0].step_sampling(ke_dev)
         stream.synchronize()
-        with torch.cuda.graph(g, stream=stream):
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             for k in range(GRAPH_STEPS):
                 if k == GRAPH_STEPS - 1:
                     reps[k % 2].step_sampling(ke_dev)
@@ -635,11 +636,12 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
             else:
                 reps[k % 2].step()
     with torch.cuda.stream(stream):                             # (made current before the region: see timed_steps)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream); ev1.record(stream)                  # (created by their first record: not inside the region)
         run(warmup, False)
         torch.cuda.synchronize(dev)
         hd.barrier()
         torch.cuda.synchronize(dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
         run(steps, True)

@@ -209,7 +209,7 @@ class ClosedLoopSim:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(self.stream):
             self.stream.synchronize()
-            with torch.cuda.graph(g, stream=self.stream):
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 for k in range(graph_steps):
                     self._step_once(sample=self.monitor is not None and k == graph_steps - 1)
         # the graph hard-codes which physical buffer is "current": valid only while the ping-pong is in this phase

@@ -157,3 +157,24 @@ def test_plugin_own_host_cost_is_reported_separately(native_built):
     assert own["prims"] == 20 and own["apply_calls"] >= 1500
     assert 0 < own["prepared_launch_alone_us"] <= own["plugin_own_us_per_step"] < full["us_per_physics_step"]
     assert own["plugin_own_us_per_step"] < 25.0               # a regression guard, not a target: measured ~8-12 us
+
+
+def test_bench_four_ranks_share_the_gpu(native_built):
+    """The N = 4 shape of the driver's scaling run, rehearsed on one GPU (gloo collectives; the box allows six GPU processes):
+    four shards of 65 536 bodies of configs[3], four different weak-scaling scenes, one JSON line - and every self-check of the
+    N > 1 line green with more than two ranks (rank count, both kinetic-energy errors, shard bit-identity)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HYDRO_BENCH_SHARE_GPU="1", HYDRO_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5",
+           "--bodies", "32768", "--spinup-seconds", "0.1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 4 and d["collective_ranks"] == 4 and "x4" in d["config"]["sharding"]
+    assert d["global_kinetic_energy_rel_err_vs_host_fp64"] <= 1e-12
+    cs = d["c4_strong"]
+    assert cs["bodies_this_rank"] == 65536 and cs["kinetic_energy"]["samples"] >= 2
+    assert cs["kinetic_energy"]["rel_err_vs_host_fp64"] <= 1e-12 and cs["shards_bit_identical"] is True
