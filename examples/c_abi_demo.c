@@ -139,6 +139,9 @@ int main(int argc, char **argv)
         ncclComm_t comm;
         const int dev0 = 0;
         if (ncclCommInitAll(&comm, 1, &dev0) != ncclSuccess) { fprintf(stderr, "ncclCommInitAll failed\n"); return 8; }
+        /* a communicator belongs to the copy of RCCL that made it: hand libhydro THIS program's ncclAllReduce */
+        CHECK_HYDRO(h, hydro_bind_rccl((void *)ncclAllReduce, (void *)ncclGetErrorString));
+        if (strcmp(hydro_rccl_origin(), "hydro_bind_rccl") != 0) return 8;
         CHECK_HYDRO(h, hydro_ke_allreduce(h, comm, d_ke, stream));
         CHECK_HIP(hipStreamSynchronize(stream));
         double all[2];

@@ -105,18 +105,24 @@ rccl = ctypes.CDLL(os.environ.get("HYDRO_TEST_RCCL", "librccl.so.1"))       # wh
 comm = ctypes.c_void_p()
 dev0 = (ctypes.c_int * 1)(0)
 assert rccl.ncclCommInitAll(ctypes.byref(comm), 1, dev0) == 0
+origins = [HydroEngine.bind_rccl(rccl)]                                      # the copy that made the communicator: no guessing
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 eng.ke_allreduce(comm.value, ke, stream=side)                                # 16 bytes, on a side stream
 side.synchronize()
 ok = torch.equal(ke, local)
+origins.append(HydroEngine.bind_rccl(None))                                  # forget it: the next call looks one up by itself
+eng.ke_allreduce(comm.value, ke, stream=side)
+side.synchronize()
+ok = ok and torch.equal(ke, local)
+origins.append(eng._lib.hydro_rccl_origin().decode())
 try:
     eng.ke_allreduce(0, ke)
     refused = False
 except Exception as e:
     refused = "HYDRO_E_ARG" in str(e)
 rccl.ncclCommDestroy(comm)
-print(json.dumps({"same": bool(ok), "refused_null": refused, "ke": ke.tolist()}))
+print(json.dumps({"same": bool(ok), "refused_null": refused, "ke": ke.tolist(), "origins": origins}))
 eng.close()
 '''
 
@@ -130,3 +136,5 @@ def test_ke_allreduce_from_the_c_abi(native_built):
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert d["same"] and d["refused_null"] and d["ke"][0] > 0
+    assert d["origins"][0] == "hydro_bind_rccl" and d["origins"][1] == "unbound"
+    assert d["origins"][2] in ("the copy already loaded in the process", "librccl opened by libhydro", "HYDRO_RCCL_LIBRARY")
