@@ -208,6 +208,7 @@ def timed_steps(replicas, steps: int, warmup: int, stream, collectives: bool = F
         wall = time.perf_counter() - t0
     t = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
     hd.all_reduce_max_(t)
+    timed_steps.last_local_wall = wall                       # this rank's own interval (main() gathers them for the N > 1 line)
     return float(t.item()), float(ev0.elapsed_time(ev1))
 
 
@@ -1045,6 +1046,8 @@ def main():
     body_steps = float(n_all.item()) * args.steps
     value = body_steps / wall
     kernel_us = ev_ms * 1e3 / args.steps              # HIP events on the launch stream around the K timed steps
+    # every rank's own figures, by rank (N > 1: which GPU set the max-over-ranks time, and how far apart the boxes' GPUs are)
+    per_rank = hd.gather_rows([timed_steps.last_local_wall * 1e6 / args.steps, kernel_us], dev) if multi else None
     step_us = wall * 1e6 / args.steps                 # the interval `value` and `ms_per_step` are computed from
     bpb = BYTES_PER_BODY[coeff] + (24 if args.layout == "aos" else 0)        # the AoS entry also updates the engine's previous velocity
     # ONE clock for `value` and `roofline.frac`: algorithmic bytes per launch / (timed interval / K).  The event figure
@@ -1135,6 +1138,10 @@ def main():
                                        "sample": "failed", "error": repr(e)}
         else:
             out["cpu_baseline"] = None
+        if per_rank is not None:
+            out["per_rank"] = {"step_us": [float(x) for x in per_rank[:, 0]], "kernel_us": [float(x) for x in per_rank[:, 1]],
+                               "is": "each rank's own wall interval / steps and HIP-event time / steps, by rank: `ms_per_step` is the maximum of the "
+                                     "first; the spread is the spread of the node's GPUs (DVFS, DESIGN.md section 6), not of the software"}
         if strong is not None:
             out["c4_strong"] = strong
         if world == 1 and args.workload == "c5" and not args.bodies and not args.no_roofline_4m:
