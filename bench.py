@@ -696,6 +696,49 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
             **residency(sc.n, "f32", 2)}
 
 
+STRONG_LEG_TIMEOUT_S = 240.0
+
+
+def guarded_strong_leg(rank: int, world: int, dev, stream, args, multi: bool, headline: dict | None, json_fd: int):
+    """c4_strong_leg, with the headline protected from it.  The leg is the one part of this file that no hardware with more
+    than one GPU has ever run; it sits after the headline measurement and before the JSON line.  If a rank raises in it, or a
+    collective in it never returns, the scaling run must still deliver its headline: a watchdog thread (the main thread may
+    be blocked inside a collective, where no Python exception or signal handler runs) lets rank 0 print the line it has,
+    with `c4_strong: {"error": ...}`, and every rank leave with exit code 0 after STRONG_LEG_TIMEOUT_S (the leg itself
+    takes seconds).  A rank-local exception does the same at once."""
+    import threading
+    done = threading.Event()
+    timeout_s = float(os.environ.get("HYDRO_BENCH_STRONG_TIMEOUT", STRONG_LEG_TIMEOUT_S))
+
+    def leave(why: str):
+        sys.stderr.write(f"bench.py: rank {rank}: configs[3] leg: {why}\n")
+        sys.stderr.flush()
+        if rank == 0 and headline is not None:
+            line = dict(headline, cpu_baseline=None, c4_strong={"error": why, "baseline_config": "configs[3]"})
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os._exit(0)
+
+    def on_timeout():
+        if not done.is_set():
+            leave(f"no result after {timeout_s:.0f} s (a rank raised or a collective did not return); the headline on this line is complete")
+
+    timer = threading.Timer(timeout_s, on_timeout)
+    timer.daemon = True
+    timer.start()
+    try:
+        if os.environ.get("HYDRO_BENCH_STRONG_FAULT") == f"raise:{rank}":       # test hook (tests/test_bench_gpu.py)
+            raise RuntimeError("injected fault")
+        if os.environ.get("HYDRO_BENCH_STRONG_FAULT") == f"hang:{rank}":
+            time.sleep(3600)
+        return c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup, collectives=multi)
+    except Exception as e:                                  # noqa: BLE001 - the other ranks may be inside a collective: leave, do not wait
+        done.set()
+        leave(f"{e!r} on rank {rank}; the headline on this line is complete")
+    finally:
+        done.set()
+        timer.cancel()
+
+
 def gather_digests(digest: list[int], dev) -> list[list[int]]:
     """Every rank's 32-byte digest, by rank (distributed.gather_rows: exact, order-independent)."""
     return [[int(x) for x in row] for row in hd.gather_rows(digest, dev, dtype=torch.int64).tolist()]
@@ -1071,11 +1114,7 @@ def main():
     host_ke = [math.fsum(host_ke[:, k].tolist()) for k in range(2)]
     ke_rel_err = max(abs(float(ke[k]) - host_ke[k]) / host_ke[k] for k in range(2))
 
-    # N > 1: BASELINE configs[3] as stated (262 144 bodies over the N GPUs, strong scaling) on every rank
-    strong = None
-    if multi and not args.no_strong_leg:
-        strong = c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup, collectives=multi)
-
+    out = None
     if rank == 0:
         traffic = load_traffic(f"{args.workload}:{args.layout}") if world == 1 and not args.bodies else None
         out = {
@@ -1115,6 +1154,18 @@ def main():
             "global_kinetic_energy_rel_err_vs_host_fp64": ke_rel_err,
             "ke_allreduce_us": ke_us,
         }
+        if per_rank is not None:
+            out["per_rank"] = {"step_us": [float(x) for x in per_rank[:, 0]], "kernel_us": [float(x) for x in per_rank[:, 1]],
+                               "is": "each rank's own wall interval / steps and HIP-event time / steps, by rank: `ms_per_step` is the maximum of the "
+                                     "first; the spread is the spread of the node's GPUs (DVFS, DESIGN.md section 6), not of the software"}
+
+    # N > 1: BASELINE configs[3] as stated (262 144 bodies over the N GPUs, strong scaling) on every rank.  The headline is
+    # complete at this point: whatever happens to this secondary leg on hardware it has never met, rank 0 still prints it.
+    strong = None
+    if multi and not args.no_strong_leg:
+        strong = guarded_strong_leg(rank, world, dev, stream, args, multi, out, json_fd)
+
+    if rank == 0:
         if traffic:
             out["roofline"]["traffic_source"] = traffic.get("source")
         if traffic and not args.no_live_traffic and args.layout == "tiled" and world > 1:
@@ -1138,10 +1189,6 @@ def main():
                                        "sample": "failed", "error": repr(e)}
         else:
             out["cpu_baseline"] = None
-        if per_rank is not None:
-            out["per_rank"] = {"step_us": [float(x) for x in per_rank[:, 0]], "kernel_us": [float(x) for x in per_rank[:, 1]],
-                               "is": "each rank's own wall interval / steps and HIP-event time / steps, by rank: `ms_per_step` is the maximum of the "
-                                     "first; the spread is the spread of the node's GPUs (DVFS, DESIGN.md section 6), not of the software"}
         if strong is not None:
             out["c4_strong"] = strong
         if world == 1 and args.workload == "c5" and not args.bodies and not args.no_roofline_4m:
@@ -1226,9 +1273,13 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    hd.barrier()
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    # (the line is out: a rank that left early - see guarded_strong_leg - must not turn the run into a failure here)
+    try:
+        hd.barrier()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    except Exception as e:                                  # noqa: BLE001
+        sys.stderr.write(f"bench.py: rank {rank}: teardown: {e!r}\n")
 
 
 def _last_stepped(replicas, steps):
