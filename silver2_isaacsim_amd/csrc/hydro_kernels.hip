@@ -2289,7 +2289,7 @@ nccl_all_reduce_fn lookup_rccl(nccl_error_string_fn* err_fn, const char** origin
     return reinterpret_cast<nccl_all_reduce_fn>(sym);
 }
 
-nccl_all_reduce_fn bound_rccl()
+nccl_all_reduce_fn bound_rccl(nccl_error_string_fn* error_string)
 {
     std::lock_guard<std::mutex> lock(g_nccl_mutex);
     if (!g_nccl_all_reduce) {
@@ -2297,6 +2297,7 @@ nccl_all_reduce_fn bound_rccl()
         const char* origin = "unbound";
         if (nccl_all_reduce_fn fn = lookup_rccl(&err_fn, &origin)) { g_nccl_error_string = err_fn; g_nccl_origin = origin; g_nccl_all_reduce = fn; }
     }
+    *error_string = g_nccl_error_string;
     return g_nccl_all_reduce;
 }
 }  // namespace
@@ -2333,13 +2334,14 @@ int hydro_ke_allreduce(hydro_t* h, void* nccl_comm, double* ke_dev, void* stream
 {
     if (!h) return HYDRO_E_ARG;
     if (!nccl_comm || !ke_dev) return fail(h, HYDRO_E_ARG, "null communicator or buffer");
-    const nccl_all_reduce_fn all_reduce = bound_rccl();
+    nccl_error_string_fn error_string = nullptr;
+    const nccl_all_reduce_fn all_reduce = bound_rccl(&error_string);
     if (!all_reduce) return fail(h, HYDRO_E_STATE, "RCCL is not available in this process (no ncclAllReduce loaded, librccl.so not found; hydro_bind_rccl hands one over, HYDRO_RCCL_LIBRARY names one)");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     // in place, two doubles: [translational, rotational] (ncclAllReduce(count = 1..2, ncclDouble, ncclSum))
     const int rc = all_reduce(ke_dev, ke_dev, 2, kNcclFloat64, kNcclSum, nccl_comm, static_cast<hipStream_t>(stream));
     if (rc != 0) {
-        snprintf(h->err, sizeof h->err, "ncclAllReduce: %s", g_nccl_error_string ? g_nccl_error_string(rc) : "failed");
+        snprintf(h->err, sizeof h->err, "ncclAllReduce: %s", error_string ? error_string(rc) : "failed");
         return HYDRO_E_LAUNCH;
     }
     return HYDRO_OK;
