@@ -202,13 +202,14 @@ def timed_steps(replicas, steps: int, warmup: int, stream, collectives: bool = F
                 after_step(k + 1, replicas[k % len(replicas)])
         ev1.record(stream)
         torch.cuda.synchronize(dev)
+        local = time.perf_counter() - t0                    # this rank's own steps are done (before it waits for the others)
         if grouped:
             hd.barrier()
             torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
     t = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
     hd.all_reduce_max_(t)
-    timed_steps.last_local_wall = wall                       # this rank's own interval (main() gathers them for the N > 1 line)
+    timed_steps.last_local_wall = local                      # (main() gathers them for the N > 1 line)
     return float(t.item()), float(ev0.elapsed_time(ev1))
 
 
@@ -1156,8 +1157,9 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = {"step_us": [float(x) for x in per_rank[:, 0]], "kernel_us": [float(x) for x in per_rank[:, 1]],
-                               "is": "each rank's own wall interval / steps and HIP-event time / steps, by rank: `ms_per_step` is the maximum of the "
-                                     "first; the spread is the spread of the node's GPUs (DVFS, DESIGN.md section 6), not of the software"}
+                               "is": "each rank's own wall interval / steps (up to the point where ITS steps are done, before the closing barrier) and HIP-event "
+                                     "time / steps, by rank: `ms_per_step` is the slowest rank's plus the barrier; the spread is the spread of the node's "
+                                     "GPUs (DVFS, DESIGN.md section 6), not of the software"}
 
     # N > 1: BASELINE configs[3] as stated (262 144 bodies over the N GPUs, strong scaling) on every rank.  The headline is
     # complete at this point: whatever happens to this secondary leg on hardware it has never met, rank 0 still prints it.

@@ -68,7 +68,7 @@ def test_bench_two_ranks_share_the_gpu(native_built):
     assert d["config"]["bodies_per_gpu"] == 65536 and "x2" in d["config"]["sharding"]
     assert d["value"] == pytest.approx(2 * 65536 * 20 / (d["ms_per_step"] * 1e-3 * 20), rel=1e-6)
     assert d["collective_ranks"] == 2 and d["rccl_ranks"] == 0                    # gloo rehearsal: no RCCL rank in it
-    assert len(d["per_rank"]["step_us"]) == 2 and max(d["per_rank"]["step_us"]) == pytest.approx(d["ms_per_step"] * 1e3, rel=1e-9)
+    assert len(d["per_rank"]["step_us"]) == 2 and max(d["per_rank"]["step_us"]) <= d["ms_per_step"] * 1e3 * 1.0001      # (+ the closing barrier)
     assert all(k <= s * 1.0001 for k, s in zip(d["per_rank"]["kernel_us"], d["per_rank"]["step_us"]))
     assert len(d["global_kinetic_energy_J"]) == 2 and d["global_kinetic_energy_J"][0] > 0
     assert d["global_kinetic_energy_rel_err_vs_host_fp64"] <= 1e-12               # two different 65 536-body scenes, summed over the ranks
