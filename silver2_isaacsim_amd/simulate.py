@@ -31,8 +31,9 @@ class KineticEnergyMonitor:
     passes the pair as `sampled=`; no second pass over the state), or by the stand-alone `hydro_kinetic_energy*` on
     the state passed to `observe`.  The pair is then summed over the ranks on a SIDE stream -
     `all_reduce(async_op=True)`, RCCL over xGMI under backend "nccl" (16 bytes: latency, not bandwidth), gloo on a
-    pinned host copy otherwise - and copied to pinned host memory.  The step stream never waits for any of it; the
-    host picks a sample up `every` steps later (`collect()`), when it has long arrived.  The reference has no
+    pinned host copy otherwise - and copied to pinned host memory.  The step stream never waits for any of it (all it
+    does for a sample is a 16-byte device copy into the sample's slot); the host picks a sample up `every` steps later
+    (`collect()`), when it has long arrived.  The reference has no
     counterpart (single process, no reduction of any kind); its oracle is an fp64 NumPy sum.
 
     `reduce_local(out)` writes the rank's float64 pair into `out` (a tensor on `device`) using the current stream;
@@ -46,24 +47,36 @@ class KineticEnergyMonitor:
             raise ValueError("KineticEnergyMonitor needs an engine, or a device (with reduce_local=, or with observe(..., sampled=))")
         self.engine, self.every, self.rotational = engine, int(every), bool(rotational)
         self.device = torch.device(device) if device is not None else engine.device
-        self._copied = None                   # event: the side stream has taken its copy of the last `sampled` buffer
         self._reduce_local = reduce_local
         self._gpu = self.device.type == "cuda"
         self._nccl = self._gpu and hd.collective_device(self.device).type == "cuda"
         self._dev = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(slots)]
         self._host = [torch.zeros(2, dtype=torch.float64, pin_memory=self._gpu) for _ in range(slots)]
         self._side = torch.cuda.Stream(self.device) if self._gpu else None
+        # one set of events per slot, reused (creating a HIP event costs more than recording one)
+        self._ev = [tuple(torch.cuda.Event() for _ in range(3)) for _ in range(slots)] if self._gpu else None
         self._pending: list = []              # (step, slot, work handle or None, completion event or None)
         self._next_slot = 0
         self.samples: list = []               # (step, [translational, rotational]) in submission order
         self.submitted = 0
         self.waited_on_host = 0               # samples the host had to wait for (0 when `every` covers the latency)
 
+    def warm_up(self, stream=None) -> None:
+        """One full pass of the sampling pipeline per slot with a dummy pair, discarded.  The FIRST pass through it creates
+        the side stream's hardware queue, maps the pinned host buffers and (under nccl) takes RCCL's first-call path -
+        measured 0.4 ms of host time, which belongs in no timed region (bench.py's configs[3] leg times 20 steps).
+        COLLECTIVE under a process group: every rank calls it at the same point."""
+        dummy = torch.zeros(2, dtype=torch.float64, device=self.device)
+        for k in range(len(self._dev)):
+            self.observe(self.every * (k + 1), stream=stream, sampled=dummy)
+            self.collect(block=True)
+        self.samples.clear()
+        self.submitted = self.waited_on_host = self._next_slot = 0
+
     def wait_before_overwrite(self, stream=None) -> None:
-        """Order `stream` after the side stream's copy of the last `sampled` buffer: call before launching the next
-        step that writes that buffer (an event wait on the device; it has fired long before, the host never blocks)."""
-        if self._copied is not None and self._gpu:
-            (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._copied)
+        """Kept for callers of rounds 3-4: nothing to wait for any more - `observe(sampled=...)` takes its copy of the
+        caller's buffer on the step stream itself, so a later step on that stream may overwrite the buffer at once."""
+        return None
 
     def observe(self, step: int, state: torch.Tensor | None = None, stream=None, sampled: torch.Tensor | None = None) -> bool:
         """Call after physics step `step` (1-based count of completed steps) with the state that step produced - or
@@ -79,24 +92,36 @@ class KineticEnergyMonitor:
         dev_buf, host_buf = self._dev[slot], self._host[slot]
         if self._gpu:
             stream = stream if stream is not None else torch.cuda.current_stream(self.device)
-            with torch.cuda.stream(stream):
-                if sampled is None:
+            ready, _, done = self._ev[slot]                 # (the slot is free: its previous sample has been collected)
+            # The pair goes into this sample's slot ON THE STEP STREAM: the stand-alone reduction writes it there, a pair that a
+            # sampling step kernel left in the caller's buffer is copied there (16 bytes, device to device, ~3 us of the step
+            # stream's time).  The caller's buffer is then free at once - the next sampling step may overwrite it without
+            # waiting for anything.  (Rounds 3-4 made that copy on the SIDE stream and had the next sampling step wait for
+            # it, a round trip step stream -> side stream -> step stream: 12.3 against 10.7 us per step in bench.py's 20-step
+            # configs[3] leg on one GPU, profiles/r05_monitor_copy_ab.log.)
+            same = torch.cuda.current_stream(self.device) == stream
+            if sampled is None:
+                if same:
                     self._local(state, dev_buf)
-                ready = torch.cuda.Event()
-                ready.record(stream)
-            self._side.wait_event(ready)                    # the side stream, not the host, waits for the reduction
+                else:
+                    with torch.cuda.stream(stream):
+                        self._local(state, dev_buf)
+            else:
+                src = sampled if sampled.numel() == 2 else sampled[:2]
+                if same:
+                    dev_buf.copy_(src, non_blocking=True)
+                else:
+                    with torch.cuda.stream(stream):
+                        dev_buf.copy_(src, non_blocking=True)
+            ready.record(stream)
+            self._side.wait_event(ready)                    # the side stream, not the host, waits for the pair
             work = None
             with torch.cuda.stream(self._side):
-                if sampled is not None:                     # 16 bytes, device to device, on the SIDE stream
-                    dev_buf.copy_(sampled[:2], non_blocking=True)
-                    self._copied = torch.cuda.Event()
-                    self._copied.record(self._side)
                 if self._nccl:
                     work = hd.all_reduce_sum_(dev_buf, async_op=True)
                     if work is not None:
                         work.wait()                         # orders the SIDE stream after RCCL's; the host does not block
                 host_buf.copy_(dev_buf, non_blocking=True)
-                done = torch.cuda.Event()
                 done.record(self._side)
             self._pending.append((step, slot, None if self._nccl else "gloo", done))
         else:
@@ -174,6 +199,9 @@ class ClosedLoopSim:
         # replays the sampling step is the last step of the graph, so `ke_every` must be a multiple of graph_steps.
         self.monitor = KineticEnergyMonitor(self.engine, every=ke_every) if ke_every else None
         self.ke_dev = torch.zeros(2, dtype=torch.float64, device=dev) if ke_every else None
+        if self.monitor is not None:                    # (collective under a process group, like the constructor itself)
+            with torch.cuda.stream(self.stream):
+                self.monitor.warm_up(self.stream)
 
     # one physics step on the current stream context; sample=True: the step also leaves the kinetic energy of the state it
     # produces in self.ke_dev (fused step: inside the kernel; two-kernel path: the stand-alone reduction afterwards)
