@@ -190,7 +190,7 @@ def test_headline_survives_a_failing_strong_leg(native_built, fault):
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    env = dict(os.environ, HYDRO_BENCH_SHARE_GPU="1", HYDRO_DIST_BACKEND="gloo", HYDRO_BENCH_STRONG_FAULT=fault, HYDRO_BENCH_STRONG_TIMEOUT="20")
+    env = dict(os.environ, HYDRO_BENCH_SHARE_GPU="1", HYDRO_DIST_BACKEND="gloo", HYDRO_BENCH_STRONG_FAULT=fault, HYDRO_BENCH_STRONG_TIMEOUT="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--bodies", "65536", "--spinup-seconds", "0.1"]
