@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""DEV-ONLY (GPU box): what one HIP-graph replay of G steps and one KineticEnergyMonitor.observe() cost - the host call and the
+step stream's own time (HIP events between them) - at G = 10 and 64 on the 262 144-body configs[3] scene.  Round 5: this is where
+the 0.4 ms first pass of a fresh monitor showed up (first line of the output), inside bench.py's 20-step region until
+KineticEnergyMonitor.warm_up() moved it out.      python scripts/diag_replay_cost.py"""
 import os, sys, time, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
