@@ -4,7 +4,6 @@ libhydro.so builds made by scripts/ab_variants.py build, next to the memory-only
     python scripts/ab_variants.py build base= ke512=-DHYDRO_AB_KE512=1@ke512.patch       (CPU container)
     python scripts/ab_ke.py base ke512                                                  (GPU box)  -> gpurun_out/ab_ke.log
 Rotating state sets as the bench's kinetic-energy probe (nothing cache-resident); the results must have IDENTICAL bits."""
-import ctypes
 import os
 import statistics
 import sys
