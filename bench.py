@@ -603,9 +603,10 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
     spin_up(reps, stream, 0.3)
     # A shard of 32 768 bodies is one 2.7 us launch: issued one by one the loop is bound by the host call (3.4 us), so
     # GRAPH_STEPS consecutive steps are captured into one HIP graph (the step functions are capture-safe) and the K
-    # timed steps are K // GRAPH_STEPS replays plus K % GRAPH_STEPS eager steps.  The LAST step of a replay is the
-    # kernel variant that also samples the kinetic energy of the bodies it holds (no extra pass, no extra launch);
-    # the monitor picks the pair up between replays, every ke_every / GRAPH_STEPS of them.
+    # timed steps are K // GRAPH_STEPS replays plus K % GRAPH_STEPS eager steps.  Where a sample is due at the end of a
+    # replay, the replayed graph is the one whose LAST step is the kernel variant that also samples the kinetic energy of the
+    # bodies it holds (no extra pass, no extra launch), and the monitor picks the pair up after it; the other replays are
+    # of a graph of plain steps.
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(stream):
         reps[1].step_sampling(ke_dev)                                 # (prepare outside the capture)
@@ -618,17 +619,22 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
                 else:
                     reps[k % 2].step()
         g.replay()
+        g_plain = None
+        if ke_every > GRAPH_STEPS:                              # replays at whose end no sample is due: plain steps only
+            g_plain = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_plain, stream=stream, capture_error_mode="thread_local"):
+                for k in range(GRAPH_STEPS):
+                    reps[k % 2].step()
+            g_plain.replay()
         stream.synchronize()
 
     def run(k_steps, observe):
         done = 0
         for _ in range(k_steps // GRAPH_STEPS):
-            sample = observe and (done + GRAPH_STEPS) % ke_every == 0
-            if observe:
-                mon.wait_before_overwrite(stream)              # (every replay ends in a sampling step that rewrites ke_dev)
-            g.replay()
+            due = (done + GRAPH_STEPS) % ke_every == 0
+            (g if due or g_plain is None else g_plain).replay()
             done += GRAPH_STEPS
-            if sample:
+            if due and observe:
                 mon.observe(done, stream=stream, sampled=ke_dev)
         for k in range(k_steps % GRAPH_STEPS):
             done += 1
@@ -658,7 +664,7 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
     hd.all_reduce_max_(tmax)
     wall, ev_ms = float(tmax.item()), float(ev0.elapsed_time(ev1))
     mon.collect(block=True)
-    del g
+    del g, g_plain
     last = mon.last()
     # ---- untimed: the leg checks itself ----
     # (1) the collective: the last global sample against the float64 host sum over ALL 262 144 bodies (the wrench
@@ -679,6 +685,11 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
         rows = whole.wrench_rows(full.n)
         whole.engine.close()
         identical = all(wrench_digest(rows[slice(*hd.shard_range(full.n, r, world))]) == mine[r] for r in range(world))
+    # ---- the same leg with the sample's pipeline INSIDE the step graph (untimed above, timed again here) ----
+    try:
+        resident = strong_leg_graph_resident(reps, full, sc, dev, stream, steps, warmup, ke_every, GRAPH_STEPS, collectives, host)
+    except Exception as e:                                  # noqa: BLE001 - a variant: it never costs the leg above its result
+        resident = {"error": repr(e)}
     for r in reps:
         r.engine.close()
     return {"value": full.n * steps / wall, "unit": "body-steps/s", "scaling": "strong", "baseline_config": "configs[3]",
@@ -692,6 +703,7 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
                                "how": "sampled inside the step kernel (hydro_step_wrench_tiled_ke, last step of a graph replay), "
                                       "all_reduce(async_op=True) + pinned copy on a side stream; checked against a float64 "
                                       "host sum over all bodies of the scene"},
+            "graph_resident_sampling": resident,
             "shards_bit_identical": identical,
             "shards_checked": "blake2b digests of every rank's (n_shard, 6) fp32 wrench == the same rows of the unsharded 262 144-body "
                               "scene stepped once on rank 0 (untimed)",
@@ -740,6 +752,86 @@ def guarded_strong_leg(rank: int, world: int, dev, stream, args, multi: bool, he
     finally:
         done.set()
         timer.cancel()
+
+
+def strong_leg_graph_resident(reps, full, sc, dev, stream, steps: int, warmup: int, ke_every: int, graph_steps: int, collectives: bool, host_ke):
+    """The configs[3] leg once more, with every sample's pipeline CAPTURED INTO THE STEP GRAPH (KineticEnergyMonitor.capture_sample):
+    the replay that ends in a sampling step also carries the RCCL all-reduce of the pair and its copy to pinned host memory, so a
+    sample costs the host nothing - in the host-driven form above the host spends 30-70 us per sample between two replays, which is
+    what a 20-step region of 3-7 us steps is bound by.  Two sampling graphs (ring slots 0 / 1) alternate, a plain one runs where no
+    sample is due.  Needs a device-side collective (backend nccl) or no group; under gloo it is skipped.  Same region protocol
+    (barrier + synchronize pairs, max over ranks), same check against the float64 host sum."""
+    from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
+    mon = KineticEnergyMonitor(reps[0].engine, every=ke_every)
+    if not mon.graph_capturable:
+        return {"skipped": "the collectives of this run are on the CPU (gloo): nothing to capture"}
+    G = graph_steps
+    graphs, plain = [], None
+    with torch.cuda.stream(stream):
+        mon.warm_up(stream)
+        for j in (0, 1):
+            reps[(G - 1) % 2].step_sampling(mon.slot_buffer(j))          # (prepare outside the captures)
+        stream.synchronize()
+        for j in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                for k in range(G):
+                    if k == G - 1:
+                        reps[k % 2].step_sampling(mon.slot_buffer(j))
+                    else:
+                        reps[k % 2].step()
+                mon.capture_sample(j)
+            graphs.append(g)
+        if ke_every > G:
+            plain = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(plain, stream=stream, capture_error_mode="thread_local"):
+                for k in range(G):
+                    reps[k % 2].step()
+        for g in graphs + ([plain] if plain is not None else []):
+            g.replay()
+        stream.synchronize()
+
+    def run(k_steps, observe):
+        done = sampled = 0
+        for _ in range(k_steps // G):
+            if (done + G) % ke_every == 0:
+                j = sampled % 2
+                mon.reserve(j)
+                graphs[j].replay()
+                done += G
+                if observe:
+                    mon.submit_captured(done, j, stream)
+                sampled += 1
+            else:
+                plain.replay()
+                done += G
+        for k in range(k_steps % G):
+            reps[k % 2].step()
+    with torch.cuda.stream(stream):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream); ev1.record(stream)
+        run(warmup, False)
+        torch.cuda.synchronize(dev)
+        hd.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(steps, True)
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        hd.barrier()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+    tmax = torch.tensor([wall], dtype=torch.float64, device=hd.collective_device(dev) if collectives else "cpu")
+    hd.all_reduce_max_(tmax)
+    wall = float(tmax.item())
+    mon.collect(block=True)
+    last = mon.last()
+    rel = max(abs(last[1][k] - host_ke[k]) / host_ke[k] for k in range(2)) if last else None
+    return {"value": full.n * steps / wall, "ms_per_step": wall * 1e3 / steps, "kernel_us_rank0": float(ev0.elapsed_time(ev1)) * 1e3 / steps,
+            "samples": len(mon.samples), "sampled_at_steps": [s_ for s_, _ in mon.samples], "rel_err_vs_host_fp64": rel,
+            "mode": f"hipGraph x{G} steps per replay; a sampling replay carries the all-reduce and the pinned copy of its sample",
+            "is": "the same leg with the sample pipeline captured into the step graph (KineticEnergyMonitor.capture_sample): no host work per sample"}
 
 
 def gather_digests(digest: list[int], dev) -> list[list[int]]:

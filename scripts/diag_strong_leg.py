@@ -23,4 +23,5 @@ for steps, warmup in ((20, 5), (20, 5), (600, 8)):
     r = bench.c4_strong_leg(0, 1, dev, stream, steps, warmup, collectives=use_nccl)
     ke = r["kinetic_energy"]
     print(json.dumps({"group": "nccl x1" if use_nccl else "none", "steps": steps, "ms_per_step_us": r["ms_per_step"] * 1e3, "kernel_us": r["kernel_us_rank0"],
-                      "samples": ke["samples"], "host_waits": ke["host_waits"], "mode": r["mode"], "rel": ke["rel_err_vs_host_fp64"]}), flush=True)
+                      "samples": ke["samples"], "host_waits": ke["host_waits"], "mode": r["mode"], "rel": ke["rel_err_vs_host_fp64"],
+                      "graph_resident": {k: v for k, v in r["graph_resident_sampling"].items() if k not in ("mode", "is")}}), flush=True)

@@ -73,6 +73,45 @@ class KineticEnergyMonitor:
         self.samples.clear()
         self.submitted = self.waited_on_host = self._next_slot = 0
 
+    # ---- graph-resident sampling: the whole pipeline of a sample captured into the caller's HIP graph -------------------------
+    @property
+    def graph_capturable(self) -> bool:
+        """True when a sample's pipeline can live inside a HIP graph: on a GPU, with the collective on the device (RCCL under
+        backend nccl - RCCL kernels are capturable) or without a process group.  False under gloo (a CPU collective)."""
+        return self._gpu and (self._nccl or not hd._collectives_on())
+
+    def slot_buffer(self, slot: int) -> torch.Tensor:
+        """The float64 device pair of ring slot `slot`: pass it as `ke_out=` to the sampling step that is being captured."""
+        return self._dev[slot]
+
+    def capture_sample(self, slot: int) -> None:
+        """Call INSIDE a graph capture, on the capturing stream, right after the sampling step that wrote `slot_buffer(slot)`:
+        records the rest of the sample's pipeline into the graph - the all-reduce over the ranks (RCCL; the capturing stream
+        joins it) and the 16-byte copy to pinned host memory.  A replay of that graph then takes the sample with NO host
+        work at all (the host-driven `observe` costs 30-70 us of host time per sample, which is what bounds a short region
+        of small steps); `submit_captured` tells the monitor after each replay.  COLLECTIVE under a process group: every
+        rank captures and replays the same graphs in the same order."""
+        if not self.graph_capturable:
+            raise RuntimeError("capture_sample needs a device-side collective (backend nccl) or no process group")
+        dev_buf = self._dev[slot]
+        if self._nccl:
+            hd.all_reduce_sum_(dev_buf)                     # (not async: the capturing stream is ordered after RCCL's)
+        self._host[slot].copy_(dev_buf, non_blocking=True)
+
+    def reserve(self, slot: int) -> None:
+        """Before replaying a graph that samples into `slot`: make sure the previous sample of that slot has been picked up
+        (it has, long ago, unless replays that sample come back to back - then this waits for it)."""
+        while any(p[1] == slot for p in self._pending):
+            self.collect(block_oldest=True)
+
+    def submit_captured(self, step: int, slot: int, stream=None) -> None:
+        """After a replay of a graph that carries `capture_sample(slot)`: the sample of physics step `step` is on its way."""
+        stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        done = self._ev[slot][2]
+        done.record(stream)
+        self._pending.append((step, slot, None, done))
+        self.submitted += 1
+
     def wait_before_overwrite(self, stream=None) -> None:
         """Kept for callers of rounds 3-4: nothing to wait for any more - `observe(sampled=...)` takes its copy of the
         caller's buffer on the step stream itself, so a later step on that stream may overwrite the buffer at once."""

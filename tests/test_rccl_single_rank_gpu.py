@@ -83,6 +83,12 @@ def test_bench_strong_leg_over_rccl(native_built, steps, warmup, every, samples)
     assert cs["bodies_this_rank"] == 262144 and ke["every_steps"] == every and ke["samples"] == samples and ke["samples"] >= 2
     assert ke["host_waits"] == 0 or steps == 20        # (a 20-step region is over before the first sample has landed: collect(block=True) waits once or twice)
     assert ke["rel_err_vs_host_fp64"] <= 1e-12 and cs["shards_bit_identical"] is True
+    # the same leg with each sample's pipeline - RCCL all-reduce and pinned copy included - captured into the step graph
+    gr = cs["graph_resident_sampling"]
+    assert "error" not in gr and gr["samples"] == samples and gr["rel_err_vs_host_fp64"] <= 1e-12, gr
+    assert gr["sampled_at_steps"] == ke["sampled_at_steps"]
+    if steps == 20:
+        assert gr["ms_per_step"] < cs["ms_per_step"]       # no host work per sample: the short region is where it shows
     assert d["global_kinetic_energy_rel_err_vs_host_fp64"] <= 1e-12
     assert d["collectives"] == "nccl (RCCL), 1 rank(s)" and d["rccl_ranks"] == 1 and d["collective_ranks"] == 1
     assert d["barrier"] == "node-local shared-memory epoch barrier"      # built over the RCCL group's own collectives
