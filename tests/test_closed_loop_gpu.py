@@ -265,3 +265,56 @@ def test_kinetic_energy_monitor_in_the_closed_loop(native_built):
     assert eager.monitor.samples[0][1][0] == pytest.approx(expect[0], rel=1e-12)
     for s in (plain, watched, ref, eager):
         s.close()
+
+
+def test_graph_resident_sampling_takes_samples_without_host_work(native_built):
+    """KineticEnergyMonitor.capture_sample: the rest of a sample's pipeline (the all-reduce over the ranks - none here - and the
+    copy to pinned host memory) is captured into the caller's HIP graph behind the sampling step; a replay takes the sample,
+    the host only records an event (`submit_captured`).  Two graphs alternate between two ring slots; `reserve` keeps a slot's
+    previous sample from being overwritten before it was picked up.  Samples equal the fp64 host sum of the state they saw."""
+    import torch
+    from silver2_isaacsim_amd.engine import HydroEngine
+    from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
+    dev = torch.device("cuda:0")
+    sc = scenes.scene_c4(n=50000, seed=41)
+    eng = HydroEngine(sc.n, dev, sc.rho, sc.g)
+    eng.set_params(sc.params)
+    states = []
+    for k in range(3):                                    # three different states: a stale sample would show
+        st = sc.state.copy(); st[:, 7:10] *= (1.0 + 0.25 * k)
+        states.append(st)
+    cur = torch.from_numpy(scenes.to_tiled(states[0])).to(dev)
+    prev = torch.from_numpy(scenes.to_tiled(sc.prev)).to(dev)
+    out = eng.alloc_tiled(6, sc.n)
+    mon = KineticEnergyMonitor(eng, every=4)
+    assert mon.graph_capturable                            # a GPU, no process group
+    stream = torch.cuda.Stream(dev)
+    graphs = []
+    with torch.cuda.stream(stream):
+        mon.warm_up(stream)
+        for j in (0, 1):
+            eng.step_wrench_tiled(cur, sc.n, sc.dt, out=out, prev=prev, ke_out=mon.slot_buffer(j), rotational=True)
+        stream.synchronize()
+        for j in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                for k in range(4):
+                    eng.step_wrench_tiled(cur, sc.n, sc.dt, out=out, prev=prev,
+                                          ke_out=mon.slot_buffer(j) if k == 3 else None, rotational=True)
+                mon.capture_sample(j)
+            graphs.append(g)
+        want = []
+        for r in range(6):                                 # six replays back to back, the state changes under them
+            stream.synchronize()
+            st = states[r % 3]
+            cur.copy_(torch.from_numpy(scenes.to_tiled(st)).to(dev))
+            want.append(scenes.kinetic_energy_fp64(st, sc.params))
+            j = r % 2
+            mon.reserve(j)
+            graphs[j].replay()
+            mon.submit_captured(4 * (r + 1), j, stream)
+    mon.collect(block=True)
+    assert [s for s, _ in mon.samples] == [4, 8, 12, 16, 20, 24] and mon.submitted == 6
+    for (_, ke), w in zip(mon.samples, want):
+        assert ke[0] == pytest.approx(w[0], rel=1e-12) and ke[1] == pytest.approx(w[1], rel=1e-12)
+    eng.close()
