@@ -8,7 +8,9 @@ the reference's `benchmark_rtf.py` does (sim time / wall time).  One physics ste
 `hydro_step_wrench_tiled` followed by `hydro_integrate_tiled`, same bits).  The previous velocity is
 read in place from the other state buffer.  All entry points are capture-safe, so K consecutive steps become ONE host
 call (`graph_steps`), which is what makes small scenes (launch-bound at ~8 us per ctypes launch) run
-at the kernels' own pace.
+at the kernels' own pace.  With a kinetic-energy monitor (`ke_every`) a replay that ends on a sampling point is of a graph
+that also carries that sample's whole pipeline - sampling step, all-reduce over the ranks, copy to pinned memory
+(`KineticEnergyMonitor.capture_sample`) - wherever the collective can live in a graph (RCCL, or no process group).
 """
 from __future__ import annotations
 
@@ -128,6 +130,7 @@ class KineticEnergyMonitor:
         self.collect(block_oldest=len(self._pending) >= len(self._dev) - 1)      # free a slot if the ring is full
         slot = self._next_slot
         self._next_slot = (slot + 1) % len(self._dev)
+        self.reserve(slot)                                  # (graph-resident samples use slots 0 / 1 of the same ring)
         dev_buf, host_buf = self._dev[slot], self._host[slot]
         if self._gpu:
             stream = stream if stream is not None else torch.cuda.current_stream(self.device)
@@ -233,6 +236,8 @@ class ClosedLoopSim:
         self._graph = None
         self._graph_steps = 0
         self._graph_bufs = None
+        self._graph_sampling: list = []
+        self._captured_samples = 0
         # optional global kinetic energy every `ke_every` steps (asynchronous, see KineticEnergyMonitor).  The fused
         # step SAMPLES it for the bodies it has in registers (ke_out=): no extra pass over the state.  With HIP-graph
         # replays the sampling step is the last step of the graph, so `ke_every` must be a multiple of graph_steps.
@@ -244,16 +249,16 @@ class ClosedLoopSim:
 
     # one physics step on the current stream context; sample=True: the step also leaves the kinetic energy of the state it
     # produces in self.ke_dev (fused step: inside the kernel; two-kernel path: the stand-alone reduction afterwards)
-    def _step_once(self, sample: bool = False) -> None:
+    def _step_once(self, sample: bool = False, ke_out: torch.Tensor | None = None) -> None:
         e = self.engine
+        ke_out = (ke_out if ke_out is not None else self.ke_dev) if sample else None
         if self.fused:
-            e.step_fused_tiled(self.cur, self.old, self.n, self.dt, implicit_drag=self.implicit_drag,
-                               ke_out=self.ke_dev if sample else None)                              # new state -> old buffer
+            e.step_fused_tiled(self.cur, self.old, self.n, self.dt, implicit_drag=self.implicit_drag, ke_out=ke_out)   # new state -> old buffer
         else:
             e.step_wrench_tiled(self.cur, self.n, self.dt, out=self.wrench, prev=self.old)
             e.integrate_tiled(self.cur, self.wrench, self.n, self.dt, state_out=self.old)   # overwrite the old buffer
             if sample:
-                e.kinetic_energy(self.old, True, out=self.ke_dev)
+                e.kinetic_energy(self.old, True, out=ke_out)
         self.cur, self.old = self.old, self.cur
 
     def run_eager(self, steps: int) -> None:
@@ -273,14 +278,33 @@ class ClosedLoopSim:
         if self.monitor is not None and self.monitor.every % graph_steps:
             raise ValueError(f"ke_every ({self.monitor.every}) must be a multiple of graph_steps ({graph_steps}): with graph "
                              f"replays the kinetic energy is sampled by the last step of a replay")
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(self.stream):
-            self.stream.synchronize()
+        # One graph of PLAIN steps, replayed wherever no sample is due at its end; with a monitor, sampling graphs for the
+        # replays that end on a sampling point.  Where the collective can live in a graph (backend nccl, or no group:
+        # KineticEnergyMonitor.graph_capturable) there are two of them, one per ring slot 0 / 1, and each carries the WHOLE
+        # pipeline of its sample - the sampling step writes the slot's device pair, the all-reduce over the ranks and the
+        # copy to pinned host memory follow inside the capture (capture_sample): a replay takes the sample, the host only
+        # records an event.  Otherwise (gloo) one sampling graph leaves the pair in self.ke_dev and the host drives the rest
+        # (observe).  COLLECTIVE under a process group, like every replay of a sampling graph.
+        def capture(sample_into=None, slot=None):
+            g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 for k in range(graph_steps):
-                    self._step_once(sample=self.monitor is not None and k == graph_steps - 1)
-        # the graph hard-codes which physical buffer is "current": valid only while the ping-pong is in this phase
-        self._graph, self._graph_steps, self._graph_bufs = g, graph_steps, (self.cur.data_ptr(), self.old.data_ptr())
+                    self._step_once(sample=sample_into is not None and k == graph_steps - 1, ke_out=sample_into)
+                if slot is not None:
+                    self.monitor.capture_sample(slot)
+            return g
+        with torch.cuda.stream(self.stream):
+            self.stream.synchronize()
+            plain = capture()
+            sampling = []
+            if self.monitor is not None:
+                if self.monitor.graph_capturable:
+                    sampling = [capture(self.monitor.slot_buffer(j), j) for j in (0, 1)]
+                else:
+                    sampling = [capture(self.ke_dev)]
+        # the graphs hard-code which physical buffer is "current": valid only while the ping-pong is in this phase
+        self._graph, self._graph_steps, self._graph_bufs = plain, graph_steps, (self.cur.data_ptr(), self.old.data_ptr())
+        self._graph_sampling = sampling
 
     def run(self, steps: int, graph_steps: int = 64) -> None:
         """Advance `steps` physics steps; full groups of `graph_steps` are graph replays."""
@@ -291,14 +315,24 @@ class ClosedLoopSim:
             # would step the stale one - recapture for the phase the ping-pong is in now)
             if self._graph is None or self._graph_steps != graph_steps or self._graph_bufs != (self.cur.data_ptr(), self.old.data_ptr()):
                 self._capture(graph_steps)              # capturing records, it does not execute
+            mon = self.monitor
             with torch.cuda.stream(self.stream):
                 for _ in range(steps // graph_steps):
-                    if self.monitor:
-                        self.monitor.wait_before_overwrite(self.stream)
-                    self._graph.replay()
-                    self.steps_done += graph_steps
-                    if self.monitor:
-                        self.monitor.observe(self.steps_done, stream=self.stream, sampled=self.ke_dev)
+                    due = mon is not None and (self.steps_done + graph_steps) % mon.every == 0
+                    if not due:
+                        self._graph.replay()
+                        self.steps_done += graph_steps
+                    elif mon.graph_capturable:                      # the sample rides in the graph: no host work
+                        j = self._captured_samples % 2
+                        mon.reserve(j)
+                        self._graph_sampling[j].replay()
+                        self.steps_done += graph_steps
+                        mon.submit_captured(self.steps_done, j, self.stream)
+                        self._captured_samples += 1
+                    else:
+                        self._graph_sampling[0].replay()
+                        self.steps_done += graph_steps
+                        mon.observe(self.steps_done, stream=self.stream, sampled=self.ke_dev)
             steps %= graph_steps
         if steps:
             self.run_eager(steps)
@@ -366,4 +400,5 @@ class ClosedLoopSim:
 
     def close(self) -> None:
         self._graph = None
+        self._graph_sampling = []
         self.engine.close()

@@ -258,6 +258,18 @@ def test_kinetic_energy_monitor_in_the_closed_loop(native_built):
         assert ke[0] == pytest.approx(want, rel=1e-12), step
         assert ke[1] > 0.0                                            # rotational part (box inertia)
     assert np.array_equal(plain.state(), watched.state())
+    # without a process group the samples ride INSIDE the replayed graphs (two sampling graphs, ring slots 0 / 1): no host work
+    assert watched.monitor.graph_capturable and len(watched._graph_sampling) == 2 and watched._captured_samples == 4
+    # a sample every SECOND replay: the replays in between are of the plain graph (no sampling kernel at all)
+    sparse = ClosedLoopSim(sc, ke_every=128)
+    sparse.run(256, graph_steps=64)
+    sparse.synchronize()
+    sparse.monitor.collect(block=True)
+    assert [s for s, _ in sparse.monitor.samples] == [128, 256] and sparse._captured_samples == 2
+    assert sparse.monitor.samples[0][1][0] == pytest.approx(expect[1], rel=1e-12)
+    assert sparse.monitor.samples[1][1][0] == pytest.approx(expect[3], rel=1e-12)
+    assert np.array_equal(plain.state(), sparse.state())
+    sparse.close()
     # eager stepping samples at the same steps
     eager = ClosedLoopSim(sc, ke_every=64)
     eager.run_eager(130)

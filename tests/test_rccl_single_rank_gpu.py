@@ -37,7 +37,8 @@ for _ in range(4):
 t = torch.tensor([2.5], dtype=torch.float64, device="cuda:0")
 hd.all_reduce_max_(t); hd.barrier()
 print(json.dumps({"steps": [s for s, _ in sim.monitor.samples], "ke": [v[0] for _, v in sim.monitor.samples], "want": want,
-                  "host_waits": sim.monitor.waited_on_host, "max": float(t.item())}))
+                  "host_waits": sim.monitor.waited_on_host, "max": float(t.item()),
+                  "captured": sim._captured_samples, "capturable": sim.monitor.graph_capturable}))
 sim.close(); ref.close()
 dist.destroy_process_group()
 '''
@@ -58,6 +59,7 @@ def test_monitor_all_reduce_goes_through_rccl(native_built):
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert d["steps"] == [64, 128, 192, 256] and d["max"] == 2.5
     assert d["ke"] == pytest.approx(d["want"], rel=1e-12)
+    assert d["capturable"] and d["captured"] == 4      # the RCCL all-reduce of every sample ran INSIDE the replayed step graph
 
 
 def _bench_over_rccl(steps, warmup):
