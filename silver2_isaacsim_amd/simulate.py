@@ -14,6 +14,7 @@ that also carries that sample's whole pipeline - sampling step, all-reduce over 
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -215,7 +216,7 @@ class KineticEnergyMonitor:
 
 class ClosedLoopSim:
     def __init__(self, scene: "scenes.Scene", device: int | str = 0, coeff_dtype: str | None = None,
-                 fused: bool = True, implicit_drag: bool = False, ke_every: int = 0):
+                 fused: bool = True, implicit_drag: bool = False, ke_every: int = 0, graph_resident_sampling: bool | None = None):
         if implicit_drag and not fused:
             raise ValueError("implicit drag needs the fused step (the drag coefficients never leave the kernel)")
         self.implicit_drag = implicit_drag
@@ -242,6 +243,11 @@ class ClosedLoopSim:
         # step SAMPLES it for the bodies it has in registers (ke_out=): no extra pass over the state.  With HIP-graph
         # replays the sampling step is the last step of the graph, so `ke_every` must be a multiple of graph_steps.
         self.monitor = KineticEnergyMonitor(self.engine, every=ke_every) if ke_every else None
+        # graph replays: may a sample's pipeline (all-reduce included) be captured into the step graph?  None = wherever it
+        # can (monitor.graph_capturable); False = always host-driven (`observe` on a side stream), e.g. should a captured
+        # collective ever misbehave on some multi-GPU installation.  HYDRO_GRAPH_SAMPLING=0 forces False.
+        want = graph_resident_sampling if graph_resident_sampling is not None else os.environ.get("HYDRO_GRAPH_SAMPLING", "1") != "0"
+        self._graph_sampling_ok = bool(want) and self.monitor is not None and self.monitor.graph_capturable
         self.ke_dev = torch.zeros(2, dtype=torch.float64, device=dev) if ke_every else None
         if self.monitor is not None:                    # (collective under a process group, like the constructor itself)
             with torch.cuda.stream(self.stream):
@@ -298,7 +304,7 @@ class ClosedLoopSim:
             plain = capture()
             sampling = []
             if self.monitor is not None:
-                if self.monitor.graph_capturable:
+                if self._graph_sampling_ok:
                     sampling = [capture(self.monitor.slot_buffer(j), j) for j in (0, 1)]
                 else:
                     sampling = [capture(self.ke_dev)]
@@ -322,7 +328,7 @@ class ClosedLoopSim:
                     if not due:
                         self._graph.replay()
                         self.steps_done += graph_steps
-                    elif mon.graph_capturable:                      # the sample rides in the graph: no host work
+                    elif self._graph_sampling_ok:                   # the sample rides in the graph: no host work
                         j = self._captured_samples % 2
                         mon.reserve(j)
                         self._graph_sampling[j].replay()

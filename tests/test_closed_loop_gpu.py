@@ -270,6 +270,14 @@ def test_kinetic_energy_monitor_in_the_closed_loop(native_built):
     assert sparse.monitor.samples[1][1][0] == pytest.approx(expect[3], rel=1e-12)
     assert np.array_equal(plain.state(), sparse.state())
     sparse.close()
+    # the host-driven form on request (what gloo gets anyway): same samples
+    driven = ClosedLoopSim(sc, ke_every=64, graph_resident_sampling=False)
+    driven.run(256, graph_steps=64)
+    driven.synchronize()
+    driven.monitor.collect(block=True)
+    assert driven._captured_samples == 0 and len(driven._graph_sampling) == 1
+    assert [(s_, v) for s_, v in driven.monitor.samples] == [(s_, v) for s_, v in watched.monitor.samples]
+    driven.close()
     # eager stepping samples at the same steps
     eager = ClosedLoopSim(sc, ke_every=64)
     eager.run_eager(130)
