@@ -27,7 +27,11 @@ timed region (every min(256, K // 2) steps) through `simulate.KineticEnergyMonit
 (device reduction + asynchronous all-reduce on a side stream).  That leg checks
 itself: `kinetic_energy.rel_err_vs_host_fp64` (gate 1e-12), `shards_bit_identical`;
 the line carries `rccl_ranks` (ranks that really joined an all-reduce of the live
-group) and the run exits non-zero when that differs from --gpus.
+group) and the run exits non-zero when that differs from --gpus.  Beside it,
+`c4_strong.graph_resident_sampling`: the same leg with each sample's pipeline (RCCL
+all-reduce and pinned copy) captured into the step graph - no host work per sample.
+The headline is complete before that leg starts and is protected from it
+(`guarded_strong_leg`: a watchdog prints it with `c4_strong.error` should the leg hang).
 
 Prints ONE JSON line on rank 0.
 """
