@@ -586,7 +586,7 @@ def wrench_digest(rows: np.ndarray) -> list[int]:
     return list(hashlib.blake2b(np.ascontiguousarray(rows, dtype=np.float32).tobytes(), digest_size=32).digest())
 
 
-def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, collectives: bool = True):
+def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, collectives: bool = True, progress: dict | None = None):
     """BASELINE.json configs[3] as it is stated: 262 144 bodies (seed 4) block-partitioned over the GPUs, every rank
     steps its contiguous shard (no data-path collective); the global kinetic energy is sampled every `ke_every`
     steps - at least twice inside the timed region, see strong_leg_cadence - by simulate.KineticEnergyMonitor: device
@@ -689,14 +689,7 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
         rows = whole.wrench_rows(full.n)
         whole.engine.close()
         identical = all(wrench_digest(rows[slice(*hd.shard_range(full.n, r, world))]) == mine[r] for r in range(world))
-    # ---- the same leg with the sample's pipeline INSIDE the step graph (untimed above, timed again here) ----
-    try:
-        resident = strong_leg_graph_resident(reps, full, sc, dev, stream, steps, warmup, ke_every, GRAPH_STEPS, collectives, host)
-    except Exception as e:                                  # noqa: BLE001 - a variant: it never costs the leg above its result
-        resident = {"error": repr(e)}
-    for r in reps:
-        r.engine.close()
-    return {"value": full.n * steps / wall, "unit": "body-steps/s", "scaling": "strong", "baseline_config": "configs[3]",
+    result = {"value": full.n * steps / wall, "unit": "body-steps/s", "scaling": "strong", "baseline_config": "configs[3]",
             "bodies_total": full.n, "bodies_this_rank": sc.n, "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": wall * 1e3 / steps, "kernel_us_rank0": ev_ms * 1e3 / steps,
             "kinetic_energy": {"every_steps": ke_every, "samples": len(mon.samples), "host_waits": mon.waited_on_host,
@@ -707,12 +700,21 @@ def c4_strong_leg(rank: int, world: int, dev, stream, steps: int, warmup: int, c
                                "how": "sampled inside the step kernel (hydro_step_wrench_tiled_ke, last step of a graph replay), "
                                       "all_reduce(async_op=True) + pinned copy on a side stream; checked against a float64 "
                                       "host sum over all bodies of the scene"},
-            "graph_resident_sampling": resident,
             "shards_bit_identical": identical,
             "shards_checked": "blake2b digests of every rank's (n_shard, 6) fp32 wrench == the same rows of the unsharded 262 144-body "
                               "scene stepped once on rank 0 (untimed)",
             "mode": f"hipGraph x{GRAPH_STEPS} steps per replay + eager remainder",
             **residency(sc.n, "f32", 2)}
+    if progress is not None:
+        progress["main"] = dict(result)                     # (the watchdog of guarded_strong_leg prints this much if the variant below hangs)
+    # ---- the same leg with the sample's pipeline INSIDE the step graph ----
+    try:
+        result["graph_resident_sampling"] = strong_leg_graph_resident(reps, full, sc, dev, stream, steps, warmup, ke_every, GRAPH_STEPS, collectives, host)
+    except Exception as e:                                  # noqa: BLE001 - a variant: it never costs the leg above its result
+        result["graph_resident_sampling"] = {"error": repr(e)}
+    for r in reps:
+        r.engine.close()
+    return result
 
 
 STRONG_LEG_TIMEOUT_S = 240.0
@@ -729,11 +731,17 @@ def guarded_strong_leg(rank: int, world: int, dev, stream, args, multi: bool, he
     done = threading.Event()
     timeout_s = float(os.environ.get("HYDRO_BENCH_STRONG_TIMEOUT", STRONG_LEG_TIMEOUT_S))
 
+    progress: dict = {}
+
     def leave(why: str):
         sys.stderr.write(f"bench.py: rank {rank}: configs[3] leg: {why}\n")
         sys.stderr.flush()
         if rank == 0 and headline is not None:
-            line = dict(headline, cpu_baseline=None, c4_strong={"error": why, "baseline_config": "configs[3]"})
+            if "main" in progress:                          # the host-driven leg had finished: only the captured variant is lost
+                strong = dict(progress["main"], graph_resident_sampling={"error": why})
+            else:
+                strong = {"error": why, "baseline_config": "configs[3]"}
+            line = dict(headline, cpu_baseline=None, c4_strong=strong)
             os.write(json_fd, (json.dumps(line) + "\n").encode())
         os._exit(0)
 
@@ -749,7 +757,9 @@ def guarded_strong_leg(rank: int, world: int, dev, stream, args, multi: bool, he
             raise RuntimeError("injected fault")
         if os.environ.get("HYDRO_BENCH_STRONG_FAULT") == f"hang:{rank}":
             time.sleep(3600)
-        return c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup, collectives=multi)
+        if os.environ.get("HYDRO_BENCH_STRONG_FAULT") == f"hang-resident:{rank}":
+            globals()["strong_leg_graph_resident"] = lambda *a, **k: time.sleep(3600)
+        return c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup, collectives=multi, progress=progress)
     except Exception as e:                                  # noqa: BLE001 - the other ranks may be inside a collective: leave, do not wait
         done.set()
         leave(f"{e!r} on rank {rank}; the headline on this line is complete")
@@ -1375,7 +1385,7 @@ def main():
 
     # (the line is out: a rank that left early - see guarded_strong_leg - must not turn the run into a failure here)
     try:
-        hd.barrier()
+        hd.barrier(timeout_s=float(os.environ.get("HYDRO_BENCH_TEARDOWN_TIMEOUT", "60")))
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
     except Exception as e:                                  # noqa: BLE001

@@ -234,15 +234,18 @@ def enable_node_barrier() -> bool:
     return _node_barrier is not None
 
 
-def barrier():
+def barrier(timeout_s: float | None = None):
     """Barrier over all ranks; no-op without a process group.  torch.distributed's own unless a measurement asked for the
-    node-local one (init_process_group(node_barrier=True) / enable_node_barrier())."""
+    node-local one (init_process_group(node_barrier=True) / enable_node_barrier()).  timeout_s (node-local barrier only): how
+    long to wait for a rank that never arrives before raising TimeoutError (default 120 s)."""
     if not _collectives_on():
         return
     if _node_barrier is None:
         dist.barrier()
-    else:
+    elif timeout_s is None:
         _node_barrier.wait()
+    else:
+        _node_barrier.wait(timeout_s)
 
 
 def barrier_kind() -> str:
