@@ -7,8 +7,10 @@ over the ranks asynchronously (simulate.ClosedLoopSim(ke_every=...) -> KineticEn
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/sharded_closed_loop.py
     HYDRO_DIST_BACKEND=gloo HYDRO_EXAMPLE_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 ...   (one-GPU rehearsal)
 
-Rank 0 prints one JSON line: the global kinetic energy at every sampling point, its value at the end against a float64 host
-sum over the gathered final state of ALL shards, and whether the sharded run reproduces the unsharded one bit for bit."""
+Waiting for the stream or for a sample has a deadline (`--timeout`): a rank that never joins a collective makes the others
+exit 4 with a TimeoutError naming the step and the rank, not hang.  Rank 0 prints one JSON line: the global kinetic energy at
+every sampling point, its value at the end against a float64 host sum over the gathered final state of ALL shards, and
+whether the sharded run reproduces the unsharded one bit for bit."""
 import argparse
 import json
 import os
@@ -28,6 +30,7 @@ def main(argv=None):
     ap.add_argument("--bodies", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--every", type=int, default=64)
+    ap.add_argument("--timeout", type=float, default=120.0, help="deadline (s) for the step stream and for a kinetic-energy sample")
     args = ap.parse_args(argv)
     rank, local_rank, world = hd.env_rank_world()
     hd.init_process_group()
@@ -38,10 +41,15 @@ def main(argv=None):
 
     full = scenes.scene_c2(n=args.bodies, seed=9)                     # buoys bobbing at the surface; the same scene on every rank ...
     mine = full.shard(rank, world)                                    # ... each keeps its contiguous block
-    sim = ClosedLoopSim(mine, device=dev, ke_every=args.every)        # (collective: the monitor warms its pipeline up)
-    sim.run(args.steps, graph_steps=args.every)                       # HIP-graph replays; the last step of a replay samples
-    sim.synchronize()
-    sim.monitor.collect(block=True)
+    sim = ClosedLoopSim(mine, device=dev, ke_every=args.every, sample_timeout_s=args.timeout)    # (local; the first run warms the monitor up, collectively)
+    try:
+        sim.run(args.steps, graph_steps=args.every)                   # HIP-graph replays; the last step of a replay samples
+        sim.synchronize(timeout_s=args.timeout)                       # a deadline, not a hang, should a rank never join a collective
+        sim.monitor.collect(block=True, timeout_s=args.timeout)
+    except TimeoutError as e:
+        sys.stderr.write(f"sharded_closed_loop: {e}\n")
+        sys.stderr.flush()
+        os._exit(4)                                                   # (other ranks may sit in a collective: leave, do not wait, do not retry)
     samples = sim.monitor.samples                                     # [(step, [translational, rotational])], identical on every rank
 
     # checks: gather every shard's final state on rank 0 (exact: distributed.gather_rows)

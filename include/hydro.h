@@ -44,8 +44,11 @@ extern "C" {
  * 0.6.0: hydro_step_wrench_tiled_batch (several independent scenes in one launch); the kinetic-energy entries are one
  *        launch (the final sum happens in the block that finishes last); hydro_ke_allreduce (RCCL from C)
  * 0.7.0: hydro_ke_rearm, hydro_bind_rccl / hydro_rccl_origin, hydro_debug_ke_fault; a kinetic-energy launch that does not
- *        finish leaves NaNs, never a stale pair; hydro_step_wrench validates before it allocates */
-#define HYDRO_VERSION 0x000700
+ *        finish leaves NaNs, never a stale pair; hydro_step_wrench validates before it allocates
+ * 0.7.1: hydro_debug_ke_fault is refused unless HYDRO_ENABLE_TEST_HOOKS=1 at load time; the class finishers of the
+ *        kinetic-energy reduction poison the partials they consumed; re-arming happens after the cross-stream wait and
+ *        never inside a stream capture */
+#define HYDRO_VERSION 0x000701
 
 #define HYDRO_OK         0
 #define HYDRO_E_ARG    (-1)   /* bad argument (null pointer, n > capacity, dt <= 0, misaligned ...) */
@@ -244,10 +247,14 @@ int hydro_step_components_aos(hydro_t *h, int64_t n, const float *position, cons
  * Two of them on one engine must not be in flight at once: a launch on a stream other than the previous one's is
  * ordered behind it by the library (an event wait on the device; not while either stream is being captured - keep a
  * captured graph's kinetic-energy launches on one stream).
- * A result is never stale: block 0 of every launch first overwrites out_dev[0..1] with NaNs, and only the wavefront that
- * completes the sum replaces them - a launch that did not run to its end (device reset, aborted graph) leaves NaNs.
- * After such an event the counters may be non-zero: hydro_ke_rearm zeroes them (the library does so by itself before the
- * next kinetic-energy launch whenever a HIP call on this handle has reported an error). */
+ * A launch that does not finish cannot pass for a result: block 0 of every launch first overwrites out_dev[0..1] with
+ * NaNs, and only the wavefront that completes the sum replaces them - a launch that did not run to its end (device reset,
+ * aborted graph) leaves NaNs.  After such an event the counters may be non-zero: hydro_ke_rearm zeroes them (the library
+ * does so by itself, outside stream captures, before the next kinetic-energy launch whenever a HIP call on this handle has
+ * reported an error).  Until then later launches give NaNs too: either nobody draws the last ticket, or a class is added
+ * before all of its members have published and meets the NaNs every class finisher leaves in the partials it consumed.
+ * Not covered (call hydro_ke_rearm if a launch may have died unseen): partials the unfinished launch itself had
+ * published - finite, and stale if the scene changed - read by such an early class sum. */
 int hydro_kinetic_energy(hydro_t *h, int64_t n, const float *const state[HYDRO_STATE_FIELDS], int rotational,
                          double *out_dev, void *stream);
 int hydro_kinetic_energy_tiled(hydro_t *h, int64_t n, const float *state, int64_t state_tile_stride, int rotational,
@@ -276,10 +283,11 @@ const char *hydro_rccl_origin(void);
  * in flight on another stream. */
 int hydro_ke_rearm(hydro_t *h, void *stream);
 
-/* TEST HOOK, not for production use: after a device synchronisation, write `value` into ticket counter `counter`
- * (0 = the top counter, 1 + c = class c) - the state an aborted launch leaves behind - and, if as_failed_launch, mark the
- * handle the way a failed HIP call does, so that the next kinetic-energy launch re-arms by itself
- * (tests/test_error_paths_gpu.py). */
+/* TEST HOOK, refused with HYDRO_E_STATE unless HYDRO_ENABLE_TEST_HOOKS=1 was in the environment when the library was
+ * loaded (one build, no second code path; a host that merely binds the library cannot reach a live engine through it):
+ * after a device synchronisation, write `value` into ticket counter `counter` (0 = the top counter, 1 + c = class c) - the
+ * state an aborted launch leaves behind - and, if as_failed_launch, mark the handle the way a failed HIP call does, so
+ * that the next kinetic-energy launch re-arms by itself (tests/test_error_paths_gpu.py). */
 int hydro_debug_ke_fault(hydro_t *h, int counter, uint32_t value, int as_failed_launch);
 
 /* Explicit rigid-body step standing in for PhysX in closed-loop runs:

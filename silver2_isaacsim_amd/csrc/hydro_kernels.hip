@@ -204,7 +204,12 @@ __device__ __forceinline__ float load_coef1(const void* __restrict__ p, uint32_t
 // later launch draws the "last" ticket.  So that this cannot pass for a result, block 0 POISONS `out` with NaNs before it
 // draws its ticket - ordered before the final store through the ticket chain, both write-through - and only a launch
 // that finishes overwrites them; the host re-arms the counters (hydro_ke_rearm, and by itself after any HIP error seen
-// on the handle).
+// on the handle).  The other shape of that fault - a class counter left at 0 < k < members, so that a later launch's
+// finisher adds its class k blocks too early - meets the second poison: every class finisher overwrites the partials it
+// has consumed with NaNs, so the slots the early finisher finds unwritten hold NaNs from the last launch that finished,
+// and the total is NaN.  What is NOT covered: slots the unfinished launch itself had published before it died (finite,
+// stale if the scene changed since) - a launch that dies without the library seeing a HIP error and without taking the
+// process with it; hydro_ke_rearm is the answer to that, the poison is not.
 // Scratch (doubles): [stride] translational partials | [stride] rotational | [64] + [64] class sums | counters (uint32, one
 // per 256 B): top, class 0 .. 63.
 // --------------------------------------------------------------------------
@@ -290,6 +295,14 @@ __device__ __forceinline__ void ke_block_reduce(double lin, double rot, double* 
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a += pa[k]; b += pb[k]; }
+        // consumed: leave NaNs behind (same-address atomics stay in program order).  Should a LATER launch ever add a
+        // class before all of its members have published - ticket counters an unfinished launch left at 0 < k < members
+        // and the library did not see (ke_suspect) - what it finds in the missing slots is a NaN, not this launch's pair.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = e0 + 64u * k + l;
+            if (e < members) { ke_publish(scratch + cls + kKeClasses * e, __builtin_nan("")); ke_publish(scratch + stride + cls + kKeClasses * e, __builtin_nan("")); }
+        }
     }
     a = wave_sum(a);
     b = wave_sum(b);
@@ -1515,26 +1528,34 @@ inline uint32_t* ke_counters(hydro_engine* h)
 constexpr size_t kKeCounterBytes = (1 + kKeClasses) * 256;
 
 // Before every launch that carries the kinetic-energy reduction (stand-alone or inside a step kernel), on its stream:
-//   * the ticket counters are zeroed first if anything went wrong on this handle since the last one (ke_suspect);
 //   * a launch on a stream OTHER than the previous one's is ordered behind it - the scratch and the counters are the
 //     engine's, two reductions in flight at once would draw each other's tickets.  Costs nothing while the caller stays on
 //     one stream (a pointer compare).  Not done while either stream is being captured (an event from outside a capture
-//     cannot be waited for inside one): a captured launch on a second stream stays the caller's business, as documented.
+//     cannot be waited for inside one): a captured launch on a second stream stays the caller's business, as documented;
+//   * then the ticket counters are zeroed if anything went wrong on this handle since the last one (ke_suspect) - after
+//     the wait above, and never inside a capture.
 int ke_prepare(hydro_engine* h, hipStream_t s)
 {
-    if (h->ke_suspect) {
-        HYDRO_HIP(h, hipMemsetAsync(ke_counters(h), 0, kKeCounterBytes, s), HYDRO_E_LAUNCH);
-        h->ke_suspect = false;
-    }
-    if (h->ke_launched && s != h->ke_last_stream) {
-        hipStreamCaptureStatus c_new = hipStreamCaptureStatusNone, c_old = hipStreamCaptureStatusNone;
-        const bool known = hipStreamIsCapturing(s, &c_new) == hipSuccess && hipStreamIsCapturing(h->ke_last_stream, &c_old) == hipSuccess;
-        if (known && c_new == hipStreamCaptureStatusNone && c_old == hipStreamCaptureStatusNone) {
+    hipStreamCaptureStatus c_new = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &c_new) != hipSuccess || c_new != hipStreamCaptureStatusNone;
+    // (1) order this stream behind the previous launch's FIRST: the memset below must not zero counters under a
+    //     reduction that is still running on the other stream
+    if (h->ke_launched && s != h->ke_last_stream && !capturing) {
+        hipStreamCaptureStatus c_old = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->ke_last_stream, &c_old) == hipSuccess && c_old == hipStreamCaptureStatusNone) {
             if (!h->ke_event && hipEventCreateWithFlags(&h->ke_event, hipEventDisableTiming) != hipSuccess) h->ke_event = nullptr;
+            // (the previous stream may be gone: a failed record means there is nothing left to wait for - its error, and only
+            // its error, is dropped here; an error the caller's own code left pending is not this function's to swallow)
             if (h->ke_event && hipEventRecord(h->ke_event, h->ke_last_stream) == hipSuccess)
                 HYDRO_HIP(h, hipStreamWaitEvent(s, h->ke_event, 0), HYDRO_E_LAUNCH);
         }
-        (void)hipGetLastError();               // (the previous stream may be gone: then there is nothing left to wait for)
+    }
+    // (2) re-arm after a fault seen on this handle.  Not while `s` is being captured: a memset recorded into a graph runs
+    //     at every replay, not now, and would leave an eager launch before the first replay un-rearmed - the flag stays
+    //     set and the next launch outside a capture does it (hydro_ke_rearm does it on request).
+    if (h->ke_suspect && !capturing) {
+        HYDRO_HIP(h, hipMemsetAsync(ke_counters(h), 0, kKeCounterBytes, s), HYDRO_E_LAUNCH);
+        h->ke_suspect = false;
     }
     h->ke_last_stream = s;
     h->ke_launched = true;
@@ -2356,9 +2377,14 @@ int hydro_ke_rearm(hydro_t* h, void* stream)
     return HYDRO_OK;
 }
 
+// HYDRO_ENABLE_TEST_HOOKS=1 in the environment WHEN THE LIBRARY IS LOADED (read once, by the static initialiser): the only
+// way to make hydro_debug_ke_fault do anything.  A host that merely binds the library cannot corrupt a live engine with it.
+static const bool g_test_hooks = [] { const char* v = getenv("HYDRO_ENABLE_TEST_HOOKS"); return v && v[0] == '1' && v[1] == 0; }();
+
 int hydro_debug_ke_fault(hydro_t* h, int counter, uint32_t value, int as_failed_launch)
 {
     if (!h) return HYDRO_E_ARG;
+    if (!g_test_hooks) return fail(h, HYDRO_E_STATE, "hydro_debug_ke_fault is a test hook: refused unless HYDRO_ENABLE_TEST_HOOKS=1 was set when the library was loaded");
     if (counter < 0 || counter > (int)kKeClasses) return fail(h, HYDRO_E_ARG, "counter must be 0 (top) .. 64 (class 63)");
     HYDRO_HIP(h, use_device(h->device), HYDRO_E_DEVICE);
     HYDRO_HIP(h, hipDeviceSynchronize(), HYDRO_E_LAUNCH);

@@ -9,8 +9,10 @@ the reference's `benchmark_rtf.py` does (sim time / wall time).  One physics ste
 read in place from the other state buffer.  All entry points are capture-safe, so K consecutive steps become ONE host
 call (`graph_steps`), which is what makes small scenes (launch-bound at ~8 us per ctypes launch) run
 at the kernels' own pace.  With a kinetic-energy monitor (`ke_every`) a replay that ends on a sampling point is of a graph
-that also carries that sample's whole pipeline - sampling step, all-reduce over the ranks, copy to pinned memory
-(`KineticEnergyMonitor.capture_sample`) - wherever the collective can live in a graph (RCCL, or no process group).
+that also carries that sample's whole pipeline - sampling step, copy to pinned memory (`KineticEnergyMonitor.capture_sample`) -
+where no other rank is involved; with more than one rank the sample's all-reduce is host-driven on a side stream by default
+ and capturing it into the graph is opt-in (`graph_resident_sampling=True`).  Waiting for samples or for the
+stream takes a deadline (`collect(timeout_s=)`, `synchronize(timeout_s=)`): a collective a rank never joins raises, it does not hang.
 """
 from __future__ import annotations
 
@@ -43,7 +45,7 @@ class KineticEnergyMonitor:
     the default is `engine.kinetic_energy(state, rotational, out=out)` on the state passed to `observe`."""
 
     def __init__(self, engine: HydroEngine | None = None, every: int = 64, rotational: bool = True, slots: int = 4,
-                 device: torch.device | str | None = None, reduce_local=None):
+                 device: torch.device | str | None = None, reduce_local=None, timeout_s: float | None = 300.0):
         if every <= 0 or slots < 2:
             raise ValueError("every must be positive, slots at least 2")
         if engine is None and device is None:
@@ -63,6 +65,9 @@ class KineticEnergyMonitor:
         self.samples: list = []               # (step, [translational, rotational]) in submission order
         self.submitted = 0
         self.waited_on_host = 0               # samples the host had to wait for (0 when `every` covers the latency)
+        # deadline of every wait the monitor does on its own (warm_up, a full ring, reserve); collect(timeout_s=) overrides it.
+        # None = wait without limit.  A collective that a rank never joins raises TimeoutError instead of hanging the host.
+        self.timeout_s = timeout_s
 
     def warm_up(self, stream=None) -> None:
         """One full pass of the sampling pipeline per slot with a dummy pair, discarded.  The FIRST pass through it creates
@@ -72,7 +77,10 @@ class KineticEnergyMonitor:
         dummy = torch.zeros(2, dtype=torch.float64, device=self.device)
         for k in range(len(self._dev)):
             self.observe(self.every * (k + 1), stream=stream, sampled=dummy)
-            self.collect(block=True)
+            try:
+                self.collect(block=True)
+            except TimeoutError as e:
+                raise TimeoutError(f"warm-up pass {k} of the monitor: {e}") from None
         self.samples.clear()
         self.submitted = self.waited_on_host = self._next_slot = 0
 
@@ -105,7 +113,7 @@ class KineticEnergyMonitor:
         """Before replaying a graph that samples into `slot`: make sure the previous sample of that slot has been picked up
         (it has, long ago, unless replays that sample come back to back - then this waits for it)."""
         while any(p[1] == slot for p in self._pending):
-            self.collect(block_oldest=True)
+            self.collect(block_oldest=True)                 # (under self.timeout_s)
 
     def submit_captured(self, step: int, slot: int, stream=None) -> None:
         """After a replay of a graph that carries `capture_sample(slot)`: the sample of physics step `step` is on its way."""
@@ -183,8 +191,14 @@ class KineticEnergyMonitor:
         else:
             self.engine.kinetic_energy(state, self.rotational, out=out)
 
-    def collect(self, block: bool = False, block_oldest: bool = False) -> list:
-        """Move finished samples to `samples` (all of them, waiting if need be, with block=True)."""
+    def collect(self, block: bool = False, block_oldest: bool = False, timeout_s: float | None = None) -> list:
+        """Move finished samples to `samples` (all of them, waiting if need be, with block=True).
+        timeout_s: the longest the host waits for ONE sample (a monotonic-clock poll of its completion event / work handle);
+        past it a TimeoutError names the sample's step and this rank - a collective some rank never joined must not hang
+        the host for ever.  The sample stays pending (nothing is retried, nothing re-executed); None = the monitor's own
+        `timeout_s` (300 s unless constructed otherwise; None there = wait without limit)."""
+        if timeout_s is None:
+            timeout_s = self.timeout_s
         out = []
         while self._pending:
             step, slot, work, done = self._pending[0]
@@ -194,14 +208,18 @@ class KineticEnergyMonitor:
                     if not must:
                         break
                     self.waited_on_host += 1
-                    done.synchronize()
+                    self._wait(done.query, done.synchronize, timeout_s, step, "its device pipeline (reduction, all-reduce, pinned copy)")
                 if work == "gloo":                          # ranks share nothing but the host here (tests, rehearsals)
-                    hd.all_reduce_sum_(self._host[slot])
+                    handle = hd.all_reduce_sum_(self._host[slot], async_op=timeout_s is not None)
+                    if handle is not None:
+                        self._wait(handle.is_completed, handle.wait, timeout_s, step, "the gloo all-reduce of its host pair")
+                        handle.wait()
             elif work is not None:                          # CPU + gloo: asynchronous handle
                 if not work.is_completed():
                     if not must:
                         break
                     self.waited_on_host += 1
+                    self._wait(work.is_completed, work.wait, timeout_s, step, "its all-reduce")
                 work.wait()
             self._pending.pop(0)
             block_oldest = False
@@ -210,13 +228,29 @@ class KineticEnergyMonitor:
             out.append(sample)
         return out
 
+    @staticmethod
+    def _wait(is_done, wait, timeout_s: float | None, step: int, what: str) -> None:
+        if timeout_s is None:
+            wait()
+            return
+        t_end = time.monotonic() + timeout_s
+        while not is_done():
+            if time.monotonic() > t_end:
+                rank = hd.env_rank_world()[0]
+                raise TimeoutError(f"kinetic-energy sample of step {step} on rank {rank}: {what} did not finish within "
+                                   f"{timeout_s:g} s (a rank that never joined the collective, or a stalled device)")
+            time.sleep(2e-4)
+
     def last(self):
+        """The newest sample the host has PICKED UP (collect()); a sample in flight is not in it.  ClosedLoopSim.run polls
+        collect() (non-blocking) before every sampling replay, so this lags by at most one sampling period."""
         return self.samples[-1] if self.samples else None
 
 
 class ClosedLoopSim:
     def __init__(self, scene: "scenes.Scene", device: int | str = 0, coeff_dtype: str | None = None,
-                 fused: bool = True, implicit_drag: bool = False, ke_every: int = 0, graph_resident_sampling: bool | None = None):
+                 fused: bool = True, implicit_drag: bool = False, ke_every: int = 0, graph_resident_sampling: bool | None = None,
+                 sample_timeout_s: float | None = 300.0):
         if implicit_drag and not fused:
             raise ValueError("implicit drag needs the fused step (the drag coefficients never leave the kernel)")
         self.implicit_drag = implicit_drag
@@ -242,14 +276,30 @@ class ClosedLoopSim:
         # optional global kinetic energy every `ke_every` steps (asynchronous, see KineticEnergyMonitor).  The fused
         # step SAMPLES it for the bodies it has in registers (ke_out=): no extra pass over the state.  With HIP-graph
         # replays the sampling step is the last step of the graph, so `ke_every` must be a multiple of graph_steps.
-        self.monitor = KineticEnergyMonitor(self.engine, every=ke_every) if ke_every else None
-        # graph replays: may a sample's pipeline (all-reduce included) be captured into the step graph?  None = wherever it
-        # can (monitor.graph_capturable); False = always host-driven (`observe` on a side stream), e.g. should a captured
-        # collective ever misbehave on some multi-GPU installation.  HYDRO_GRAPH_SAMPLING=0 forces False.
-        want = graph_resident_sampling if graph_resident_sampling is not None else os.environ.get("HYDRO_GRAPH_SAMPLING", "1") != "0"
-        self._graph_sampling_ok = bool(want) and self.monitor is not None and self.monitor.graph_capturable
+        self.monitor = KineticEnergyMonitor(self.engine, every=ke_every, timeout_s=sample_timeout_s) if ke_every else None
+        # graph replays: may a sample's pipeline (all-reduce included) be captured into the step graph?  By default ONLY where no
+        # other rank is involved (no process group, or a one-rank group): there a replay that samples costs the host nothing.
+        # With more than one rank the default is the host-driven pipeline (`observe`: asynchronous all-reduce on a side stream,
+        # SURVEY.md 8e - 5 us of host time per sampled step); a collective captured into a graph is OPT-IN there
+        # (graph_resident_sampling=True or HYDRO_GRAPH_SAMPLING=1) until multi-GPU hardware has run it.  False / =0: never.
+        env = os.environ.get("HYDRO_GRAPH_SAMPLING")
+        if graph_resident_sampling is not None:
+            want = bool(graph_resident_sampling)
+        elif env is not None:
+            want = env != "0"
+        else:
+            want = not hd._collectives_on() or torch.distributed.get_world_size() == 1
+        self._wants_graph_sampling = want
+        self._graph_sampling_ok = want and self.monitor is not None and self.monitor.graph_capturable
         self.ke_dev = torch.zeros(2, dtype=torch.float64, device=dev) if ke_every else None
-        if self.monitor is not None:                    # (collective under a process group, like the constructor itself)
+        self._monitor_warm = self.monitor is None
+
+    def _warm_monitor(self) -> None:
+        """First run*() with a monitor: one discarded pass of the sampling pipeline per slot (side-stream queue, pinned
+        mappings, RCCL's first call).  COLLECTIVE under a process group - like every run that samples, and unlike the
+        constructor, which is local: ranks may build their sims in any order."""
+        if not self._monitor_warm:
+            self._monitor_warm = True
             with torch.cuda.stream(self.stream):
                 self.monitor.warm_up(self.stream)
 
@@ -268,6 +318,7 @@ class ClosedLoopSim:
         self.cur, self.old = self.old, self.cur
 
     def run_eager(self, steps: int) -> None:
+        self._warm_monitor()
         with torch.cuda.stream(self.stream):
             for _ in range(steps):
                 sample = self.monitor is not None and (self.steps_done + 1) % self.monitor.every == 0
@@ -313,7 +364,9 @@ class ClosedLoopSim:
         self._graph_sampling = sampling
 
     def run(self, steps: int, graph_steps: int = 64) -> None:
-        """Advance `steps` physics steps; full groups of `graph_steps` are graph replays."""
+        """Advance `steps` physics steps; full groups of `graph_steps` are graph replays.  With a monitor under a process
+        group this is COLLECTIVE (every rank runs the same number of steps with the same cadence)."""
+        self._warm_monitor()
         if graph_steps and steps >= graph_steps:
             if self.steps_done % graph_steps and self.monitor is not None:
                 raise ValueError("with a kinetic-energy monitor, graph replays must start at a multiple of graph_steps")
@@ -330,6 +383,7 @@ class ClosedLoopSim:
                         self.steps_done += graph_steps
                     elif self._graph_sampling_ok:                   # the sample rides in the graph: no host work
                         j = self._captured_samples % 2
+                        mon.collect()                               # (non-blocking, ~1 us: finished samples become visible to last())
                         mon.reserve(j)
                         self._graph_sampling[j].replay()
                         self.steps_done += graph_steps
@@ -356,6 +410,7 @@ class ClosedLoopSim:
         if self.monitor is not None and (self.monitor.every % chunk or self.steps_done % chunk):
             raise ValueError(f"ke_every ({self.monitor.every}) must be a multiple of chunk ({chunk}) and the run must start "
                              f"at one: the kinetic energy is sampled by the last step of a launch")
+        self._warm_monitor()
         with torch.cuda.stream(self.stream):
             while steps > 0:
                 k = min(chunk, steps)
@@ -370,8 +425,21 @@ class ClosedLoopSim:
                 if sample:
                     self.monitor.observe(self.steps_done, stream=self.stream, sampled=self.ke_dev)
 
-    def synchronize(self) -> None:
-        self.stream.synchronize()
+    def synchronize(self, timeout_s: float | None = None) -> None:
+        """Wait for everything submitted to the step stream.  timeout_s: poll an event against a monotonic clock instead of
+        blocking in the driver, and raise TimeoutError (naming the step count and this rank) past it - a captured collective
+        that some rank never replays would otherwise hang the host with no deadline."""
+        if timeout_s is None:
+            self.stream.synchronize()
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        t_end = time.monotonic() + timeout_s
+        while not ev.query():
+            if time.monotonic() > t_end:
+                raise TimeoutError(f"closed loop on rank {hd.env_rank_world()[0]}: the step stream had not drained {timeout_s:g} s after "
+                                   f"step {self.steps_done} was submitted (a collective some rank never joined, or a stalled device)")
+            time.sleep(2e-4)
 
     def state(self) -> np.ndarray:
         """(N,13) host copy of the current state."""

@@ -8,6 +8,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# hydro_debug_ke_fault (tests/test_error_paths_gpu.py) is refused unless this is set WHEN libhydro.so IS LOADED - which is
+# once per process, by whichever test first makes an engine: hence here and not in that test
+os.environ.setdefault("HYDRO_ENABLE_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

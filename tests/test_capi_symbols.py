@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(native_built):
     assert sorted(_native.SIGNATURES) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.hydro_version() == 0x000700
+    assert lib.hydro_version() == 0x000701
     assert lib.hydro_status_string(0) == b"HYDRO_OK"
     assert lib.hydro_status_string(-5) == b"HYDRO_E_STATE"
 

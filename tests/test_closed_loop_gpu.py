@@ -361,3 +361,48 @@ def test_sharded_closed_loop_example_two_ranks(native_built):
     assert d["ranks"] == 2 and d["bodies"] == 20001 and d["bodies_per_rank"] == 10001
     assert [k["step"] for k in d["kinetic_energy_J"]] == [64, 128]
     assert d["last_sample_rel_err_vs_host_fp64"] <= 1e-12 and d["sharded_equals_unsharded_bit_for_bit"] is True
+
+
+def test_a_rank_that_never_joins_a_sample_is_a_timeout_not_a_hang(native_built):
+    """the product has the deadline the bench has.  Two ranks of the sharded example on this box's GPU
+    (gloo); rank 1 stalls before its first replay, so the all-reduce of rank 0's first kinetic-energy sample is never joined:
+    rank 0 raises TimeoutError naming the step and the rank within `--timeout` and the job exits non-zero - no hang, no retry."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HYDRO_DIST_BACKEND="gloo", HYDRO_EXAMPLE_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "_stalled_rank_worker.py"), "--bodies", "20001", "--steps", "128",
+           "--timeout", "5"]
+    t0 = time.monotonic()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and time.monotonic() - t0 < 120
+    assert "kinetic-energy sample of step 64 on rank 0" in res.stderr and "did not finish within 5 s" in res.stderr
+    assert "warm-up pass 0" in res.stderr                           # (rank 1 stalls before its first run: the first collective is the warm-up's)
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]       # no result line from a run that did not finish
+
+
+def test_captured_collective_is_opt_in_with_more_than_one_rank(native_built, monkeypatch):
+    """Default of ClosedLoopSim's sampling under graph replays: inside the graph only where no other rank is involved; with a
+    process group of more than one rank it is the host-driven side-stream pipeline unless asked for (simulate.py)."""
+    from silver2_isaacsim_amd import distributed as hd
+    from silver2_isaacsim_amd.simulate import ClosedLoopSim
+    sc = scenes.scene_c2(n=4096, seed=3)
+    alone = ClosedLoopSim(sc, ke_every=64)
+    assert alone._graph_sampling_ok                                   # no process group: the sample rides in the graph
+    alone.close()
+    import torch.distributed as dist
+    monkeypatch.setattr(hd, "_collectives_on", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 8)
+    for kw, env, want in (({}, None, False), ({"graph_resident_sampling": True}, None, True), ({}, "1", True), ({}, "0", False),
+                          ({"graph_resident_sampling": False}, "1", False)):
+        if env is None:
+            monkeypatch.delenv("HYDRO_GRAPH_SAMPLING", raising=False)
+        else:
+            monkeypatch.setenv("HYDRO_GRAPH_SAMPLING", env)
+        sim = ClosedLoopSim(sc, ke_every=64, **kw)                    # (the constructor is local: no collective in it)
+        assert sim._wants_graph_sampling is want, (kw, env)
+        sim.engine.close()

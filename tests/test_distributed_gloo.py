@@ -182,6 +182,53 @@ def test_kinetic_energy_monitor_two_ranks():
         assert got == pytest.approx(want, rel=1e-12)
 
 
+def _deadline_worker(rank, world, port, q):
+    import sys
+    import time
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from silver2_isaacsim_amd import distributed as hd
+    from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
+    assert hd.init_process_group(backend="gloo")
+
+    def reduce_local(out):
+        out[0] = 1.0 + rank; out[1] = 0.0
+    mon = KineticEnergyMonitor(None, every=4, device="cpu", reduce_local=reduce_local, timeout_s=None)
+    mon.observe(4)                                            # both ranks join sample 1 ...
+    mon.collect(block=True, timeout_s=30.0)
+    if rank == 0:
+        mon.observe(8)                                        # ... only rank 0 submits sample 2
+        t0 = time.monotonic()
+        try:
+            mon.collect(block=True, timeout_s=1.5)
+            q.put((rank, "no timeout", 0.0, mon.samples))
+        except TimeoutError as e:
+            q.put((rank, str(e), time.monotonic() - t0, mon.samples))
+    else:
+        q.put((rank, "idle", 0.0, mon.samples))
+        time.sleep(6.0)                                       # alive (its sockets open) while rank 0 waits in vain
+    q.close(); q.join_thread()
+    os._exit(0)                                               # (a collective is outstanding on rank 0: leave without a teardown barrier)
+
+
+def test_a_sample_nobody_else_joins_raises_within_the_deadline():
+    """VERDICT r5 item 2 on the CPU: `collect(block=True, timeout_s=)` polls the sample's work handle against a monotonic
+    clock and raises TimeoutError naming the step and the rank; it does not hang, retry or re-execute anything."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deadline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=180) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+    msg, waited, samples = res[0]
+    assert "kinetic-energy sample of step 8 on rank 0" in msg and "did not finish within 1.5 s" in msg
+    assert 1.4 <= waited < 20.0
+    assert samples == [(4, [3.0, 0.0])] and res[1][2] == [(4, [3.0, 0.0])]      # the first sample was summed over both ranks
+
+
 def test_kinetic_energy_monitor_single_process_cadence():
     from silver2_isaacsim_amd.simulate import KineticEnergyMonitor
     calls = []

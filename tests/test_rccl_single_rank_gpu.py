@@ -81,19 +81,20 @@ def test_bench_strong_leg_over_rccl(native_built, steps, warmup, every, samples)
     all-reduce on the side stream runs at least twice inside the timed region and the leg's self-checks hold."""
     d = _bench_over_rccl(steps, warmup)
     cs = d["c4_strong"]
-    ke = cs["kinetic_energy"]
+    ke = cs["ke"]
     assert cs["bodies_this_rank"] == 262144 and ke["every_steps"] == every and ke["samples"] == samples and ke["samples"] >= 2
     assert ke["host_waits"] == 0 or steps == 20        # (a 20-step region is over before the first sample has landed: collect(block=True) waits once or twice)
-    assert ke["rel_err_vs_host_fp64"] <= 1e-12 and cs["shards_bit_identical"] is True
+    assert ke["rel_err"] <= 1e-12 and cs["shards_bit_identical"] is True and d["ok"] is True
     # the same leg with each sample's pipeline - RCCL all-reduce and pinned copy included - captured into the step graph
-    gr = cs["graph_resident_sampling"]
-    assert "error" not in gr and gr["samples"] == samples and gr["rel_err_vs_host_fp64"] <= 1e-12, gr
+    gr = cs["captured"]
+    assert "error" not in gr and gr["samples"] == samples and gr["rel_err"] <= 1e-12, gr
     assert gr["sampled_at_steps"] == ke["sampled_at_steps"]
     if steps == 20:
         assert gr["ms_per_step"] < 1.25 * cs["ms_per_step"]    # no host work per sample: measured 9.2 vs 14.3 us (a loose bound: host timing)
-    assert d["global_kinetic_energy_rel_err_vs_host_fp64"] <= 1e-12
-    assert d["collectives"] == "nccl (RCCL), 1 rank(s)" and d["rccl_ranks"] == 1 and d["collective_ranks"] == 1
-    assert d["barrier"] == "node-local shared-memory epoch barrier"      # built over the RCCL group's own collectives
+    col = d["collective"]
+    assert col["ke_rel_err"] <= 1e-12
+    assert col["backend"] == "nccl (RCCL)" and col["rccl_ranks"] == 1 and col["ranks"] == 1
+    assert col["barrier"] == "node-local shared-memory epoch barrier"      # built over the RCCL group's own collectives
 
 
 CHILD_C_ROUTE = r'''
