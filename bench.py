@@ -247,7 +247,7 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
         cpu_model = "unknown"
     return {
         "value": single, "unit": "body-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{m} bodies of the bench scene x {reps} passes, oracle/hydro_oracle.c (fp64 C port of the Numba path), 1 thread",
+        "sample": f"{m} bodies of the bench scene x {reps} passes, oracle/hydro_oracle.c (C port of the Numba path), 1 thread",
         "all_core_value": multi, "all_cores": threads, "hardware_threads": os.cpu_count(), "cpu_model": cpu_model,
         "gpu_vs_oracle_max_rel_err": float(err.max()), "gpu_vs_oracle_n_over_1e-5": int((err > 1e-5).sum()),
         "gpu_vs_oracle_checked": int(m),

@@ -9,7 +9,7 @@ for v in dist node none; do
   port=$((port+1)); export MASTER_PORT=$port
   if [ $v = dist ]; then export HYDRO_BARRIER=dist; else unset HYDRO_BARRIER; fi
   if [ $v = none ]; then unset HYDRO_DIST_ALWAYS HYDRO_BENCH_FORCE_GROUP; else export HYDRO_DIST_ALWAYS=1 HYDRO_BENCH_FORCE_GROUP=1; fi
-  python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-extras --no-live-traffic --no-roofline-4m --no-strong-leg 2>/dev/null | python -c "
+  python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-extras --no-configs --no-live-traffic --no-roofline-4m --no-strong-leg 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']; print('$v', d.get('barrier'), round(d['ms_per_step']*1000,3), round(r['kernel_us'],3), round(r['frac'],4))"
 done; done

@@ -70,7 +70,8 @@ for kind, n, coeff, sets in CASES:
         if not hasattr(nat._lib, "hydro_set_semantics"):
             HydroEngine.set_semantics = lambda self, *_a, **_k: None
         layout = os.environ.get("HYDRO_AB_LAYOUT", "tiled")          # tiled | soa | aos (the simulator-facing entry)
-        cls = bench.AosReplica if layout == "aos" else bench.Replica
+        from scripts.bench_extras import AosReplica
+        cls = AosReplica if layout == "aos" else bench.Replica
         reps[nm] = [cls(sc, coeff, dev, roll=7919 * k, layout=layout) for k in range(sets)]
         if opt:
             import re
@@ -86,7 +87,7 @@ for kind, n, coeff, sets in CASES:
         d = (reps[nm][0].out - ref).abs().max().item()
         say(f"{kind} n={n} {coeff}: max |{nm} - {names[0]}| = {d:.3e}")
     bench.spin_up(reps[names[0]], stream, 1.0)
-    K, ROUNDS = 400 if n <= 2 ** 20 else 120, 9
+    K, ROUNDS = 400 if n <= 2 ** 20 else 120, int(os.environ.get("HYDRO_AB_ROUNDS", "9"))
     res = {nm: [] for nm in names}
     with torch.cuda.stream(stream):
         for r in range(ROUNDS):

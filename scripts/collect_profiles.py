@@ -18,6 +18,8 @@ def one(pattern):
 
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+if os.path.exists(os.path.join(src, "bench_extras.json")):          # the side file (round 6: extras no longer ride on the line)
+    shutil.copy(os.path.join(src, "bench_extras.json"), os.path.join(dst, f"{tag}_bench_extras.json"))
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_c5_kernel_stats.csv"))
 shutil.copy(one("stats/**/*domain_stats.csv"), os.path.join(dst, f"{tag}_c5_domain_stats.csv"))
 
@@ -65,6 +67,10 @@ if trace:
     mean_us = statistics.mean(x[1] for x in d[-steps:]) / 1e3
 path = os.path.join(dst, "traffic.json")
 tr = json.load(open(path))
+prev = tr.get("c5:tiled") or {}
+if prev.get("kernel_trace_timed_region_mean_us") and "c5:tiled_timings" not in tr:      # carry the last pre-round-6 record over
+    tr["c5:tiled_timings"] = {"by_tag": {"r05b": {"kernel_trace_timed_region_mean_us": prev["kernel_trace_timed_region_mean_us"],
+                                                   "in_bench_event_us_unprofiled": prev.get("in_bench_event_us", {}).get("unprofiled")}}}
 tr["c5:tiled"] = {
     "hbm_bytes_per_launch": 2.0 * fetch_raw + write_b,
     "fetch_size_bytes_raw": fetch_raw, "fetch_size_bytes_corrected": 2.0 * fetch_raw, "write_size_bytes": write_b,
@@ -77,7 +83,15 @@ tr["c5:tiled"] = {
     "kernel_trace_timed_region_mean_us": mean_us,
     "in_bench_event_us": {"unprofiled": bench["roofline"]["kernel_us"],
                           "under_kernel_trace": json.load(open(os.path.join(src, "bench_stats.json")))["roofline"]["kernel_us"]},
+    "tag": tag,
 }
+# timings are a property of the BOX a tag ran on (DVFS): kept per tag, never overwritten by the next round's run
+by_tag = (tr_old.get("by_tag") or {}) if (tr_old := tr.get("c5:tiled_timings")) else {}
+box = bench.get("box") or {}
+by_tag[tag] = {"kernel_trace_timed_region_mean_us": mean_us, "in_bench_event_us_unprofiled": bench["roofline"]["kernel_us"],
+               "frac": bench["roofline"]["frac"], "kernel_over_memory_only": box.get("kernel_over_memory_only"),
+               "clock_held_ghz": box.get("clock_held_ghz"), "throttles_under_combined_load": box.get("throttles_under_combined_load")}
+tr["c5:tiled_timings"] = {"by_tag": by_tag}
 # second roofline object: 4 194 304 bodies, fp16 coefficients
 if os.path.isdir(os.path.join(src, "fetch4m")):
     shutil.copy(one("stats4m/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_f16_4m_kernel_stats.csv"))

@@ -8,8 +8,8 @@ mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 # the simulator-facing entry (hydro_step_wrench_aos, fp32 parameters) at 1 048 576 and 4 194 304 bodies: kernel time + HBM-side bytes
-aos1="--layout aos --workload c5-f32 --steps 400 --warmup 40 --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic"
-aos1s="--layout aos --workload c5-f32 --steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras --no-roofline-4m --no-live-traffic"
+aos1="--layout aos --workload c5-f32 --steps 400 --warmup 40 --cpu-seconds 0 --no-extras --no-configs --no-roofline-4m --no-live-traffic"
+aos1s="--layout aos --workload c5-f32 --steps 40 --warmup 8 --spinup-seconds 0.2 --cpu-seconds 0 --no-extras --no-configs --no-roofline-4m --no-live-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/aos_stats" -- python3 bench.py $aos1 > "$out/bench_aos_stats.json" 2> "$out/aos_stats.err" || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/aos_fetch" -- python3 bench.py $aos1s > "$out/bench_aos_fetch.json" 2> "$out/aos_fetch.err" || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/aos_write" -- python3 bench.py $aos1s > "$out/bench_aos_write.json" 2> "$out/aos_write.err" || exit 1

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+from scripts import bench_extras  # noqa: E402
 from silver2_isaacsim_amd.engine import HydroEngine  # noqa: E402
 from silver2_isaacsim_amd.simulate import ClosedLoopSim  # noqa: E402
 
@@ -56,7 +57,7 @@ elif what == "resident":
     sim.synchronize()
     us = ev0.elapsed_time(ev1) * 1e3 / (64 * launches)
     print(json.dumps({"what": "hydro_step_fused_tiled_multi, 64 steps per launch", "n": n, "us_per_step": us,
-                      "roofline": bench.valu_roofline("resident closed loop, one step (", n, us)}))
+                      "roofline": bench_extras.valu_roofline("resident closed loop, one step (", n, us)}))
     sim.close()
 elif what == "batch":
     sc = bench.build_scene("c5", n, 11)

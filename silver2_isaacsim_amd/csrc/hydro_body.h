@@ -80,6 +80,19 @@ HYDRO_FN double rcp64(double x)
     return 1.0 / x;
 #endif
 }
+// on ? rcp64(x) : +0.0 - the select acts on the fp32 seed (one v_cndmask, not two on the fp64 result): a zero seed
+// goes through the Newton step as fma(0, fma(-x, 0, 1), 0) = +0.0 exactly (x finite)
+HYDRO_FN double rcp64_or_zero(double x, bool on)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float seed = on ? __builtin_amdgcn_rcpf((float)x) : 0.0f;
+    asm("" : "+v"(seed));                               // (keeps the select on the fp32 value: the compiler would move it behind the conversion)
+    const double r = (double)seed;
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+#else
+    return on ? 1.0 / x : 0.0;
+#endif
+}
 // Both take the seed of max(x, 1e-36): x = 0 then gives exactly 0 (0 times a finite seed) with no compare-and-select, and
 // nothing below 1e-36 is ever meaningful here (squared speeds under the model's 1e-12, products of O(1) geometry).
 HYDRO_FN double sqrt64(double x)
@@ -160,8 +173,28 @@ constexpr uint32_t lattice_mask(int axis, int value)
     return m;
 }
 
-// the bit of lattice point (i,j,k), i,j,k in {-1,0,1}
-constexpr uint32_t lattice_bit(int i, int j, int k) { return 1u << (26 - (9 * (i + 1) + 3 * (j + 1) + (k + 1))); }
+// the bit of lattice point (i,j,k), i,j,k in {-1,0,1}: its position in the mask, and the bit
+constexpr uint32_t lattice_shift(int i, int j, int k) { return 26 - (9 * (i + 1) + 3 * (j + 1) + (k + 1)); }
+constexpr uint32_t lattice_bit(int i, int j, int k) { return 1u << lattice_shift(i, j, k); }
+// bit `pos` of the mask as a flag: v_bfe_u32 with the position in a register (both candidate positions of a face pair are
+// inline constants; selecting between two BIT MASKS costs a literal move and an AND on top)
+// ... sign-extended (v_bfe_i32): 0 or ~0, which zeroes a double by two ANDs - one instruction less than compare-and-select
+HYDRO_FN uint32_t mask_bit_ext(uint32_t mask, uint32_t pos)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_sbfe((int)mask, pos, 1u);
+#else
+    return 0u - ((mask >> pos) & 1u);
+#endif
+}
+// x where keep = ~0, +0.0 where keep = 0
+HYDRO_FN double keep_or_zero(double x, uint32_t keep)
+{
+    uint64_t u; __builtin_memcpy(&u, &x, sizeof u);
+    u &= ((uint64_t)keep << 32) | keep;
+    __builtin_memcpy(&x, &u, sizeof u);
+    return x;
+}
 
 struct BodyIn {
     float px, py, pz;               // p_x, p_y are never read by the wrench (it does not depend on them)
@@ -226,7 +259,16 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     // clamp: z_hi <= 0 makes -z_lo >= height, so the quotient is >= 1 by itself, and z_lo >= 0 makes it <= 0 - which
     // `wet` below reads as dry (every output of a dry body is selected to zero at the end, A4).
     double ratio = fmin(1.0, -zlo * rcp64(height));
-    if (height < kHeightEps) ratio = (zlo < 0.0) ? 1.0 : 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (a box of zero height: practically never - a wave-uniform branch keeps its five selects out of everybody's path)
+    if (__builtin_amdgcn_ballot_w64(height < kHeightEps) != 0)
+#endif
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");                  // (a block with a side effect is not turned back into selects)
+#endif
+        if (height < kHeightEps) ratio = (zlo < 0.0) ? 1.0 : 0.0;
+    }
     o.ratio = ratio;
     o.wet = ratio > kDryEps;                            // A4 (:277-279)
 
@@ -289,15 +331,15 @@ HYDRO_FN Body solve_body(const BodyIn& b, double ax, double ay, double az, doubl
     const double fhx = fsx * hx, fhy = fsy * hy, fhz = fsz * hz;
     // (the six face centres ARE lattice points - (+-1,0,0), (0,+-1,0), (0,0,+-1) - so "centre below the surface" is a
     // bit of the keypoint mask: the same value p_z +- e_a, the same sign bit)
-    const bool wfx = wetmask & ((ux < 0.0) ? lattice_bit(1, 0, 0) : lattice_bit(-1, 0, 0));
-    const bool wfy = wetmask & ((uy < 0.0) ? lattice_bit(0, 1, 0) : lattice_bit(0, -1, 0));
-    const bool wfz = wetmask & ((uz < 0.0) ? lattice_bit(0, 0, 1) : lattice_bit(0, 0, -1));
-    const double fax = wfx ? fabs(ux) * (dy * dz) : 0.0;
-    const double fay = wfy ? fabs(uy) * (dx * dz) : 0.0;
-    const double faz = wfz ? fabs(uz) * axy_ : 0.0;
+    const uint32_t wfx = mask_bit_ext(wetmask, (ux < 0.0) ? lattice_shift(1, 0, 0) : lattice_shift(-1, 0, 0));
+    const uint32_t wfy = mask_bit_ext(wetmask, (uy < 0.0) ? lattice_shift(0, 1, 0) : lattice_shift(0, -1, 0));
+    const uint32_t wfz = mask_bit_ext(wetmask, (uz < 0.0) ? lattice_shift(0, 0, 1) : lattice_shift(0, 0, -1));
+    const double fax = keep_or_zero(fabs(ux) * (dy * dz), wfx);
+    const double fay = keep_or_zero(fabs(uy) * (dx * dz), wfy);
+    const double faz = keep_or_zero(fabs(uz) * axy_, wfz);
     const double area = fax + fay + faz;
     const bool has_area = area > kAreaEps;
-    const double inv_area = has_area ? rcp64(area) : 0.0;
+    const double inv_area = rcp64_or_zero(area, has_area);
     // body-frame CoP arm: sum of (face centre x its share of the area); without area cop = cob (:115,140).  The
     // choice is made on the body-frame vector, so one rotation serves both cases: the face term is exactly 0 without
     // area (inv_area = 0), and the CoB arm enters with weight 0 or 1.

@@ -445,31 +445,44 @@ constexpr uint32_t kPrmTileF16 = 480;
 
 // state, previous velocity and parameter records of body (tile, lane): the ~28 loads of a wave are three
 // contiguous records, every field offset in the load instruction's immediate.
+// One wavefront = one tile, so the tile index is WAVE-UNIFORM: the callers hand it over as a scalar (wave_tile below) and
+// the three record bases are scalar 64-bit adds; what is left per lane is ONE offset register for every 4-byte field of
+// every record (lane * 4) and one for the fp16 coefficients (lane * 2) - 5 vector instructions of addressing per body where
+// per-lane tile arithmetic (24-bit multiplies, add-shifts) took 15.  `st`, `pv` are the tile's records, not the buffers.
 template <bool HALF, bool NT>
-__device__ __forceinline__ void load_tile_records(const TiledArgs& a, uint32_t tile, uint32_t lane, uint32_t so, uint32_t po,
+__device__ __forceinline__ void load_tile_records(const float* __restrict__ st, const float* __restrict__ pvr, const float* __restrict__ prm_all,
+                                                  uint32_t tile, uint32_t lane4,
                                                   float (&s)[HYDRO_STATE_FIELDS], float (&pv)[HYDRO_PREV_FIELDS],
                                                   float (&d)[3], float (&c)[7], float& mass)
 {
 #pragma unroll
-    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(a.st, so, f * 256u));
+    for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) s[f] = ldg<NT>(at<float>(st, lane4, f * 256u));
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(a.pv, po, f * 256u));
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(pvr, lane4, f * 256u));
     if constexpr (HALF) {
-        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
+        const float* prm = prm_all + (size_t)tile * kPrmTileF16;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo, 3 * 256u));
-        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(prm, lane4, f * 256u));
+        mass = ldg<NT>(at<float>(prm, lane4, 3 * 256u));
+        const uint32_t lane2 = lane4 >> 1;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(a.prm, ho, f * 128u)));
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(prm, lane2, 1024u + f * 128u)));
     } else {
-        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+        const float* prm = prm_all + (size_t)tile * kPrmTileF32;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(a.prm, qo, f * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(prm, lane4, f * 256u));
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(a.prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(a.prm, qo, 10 * 256u));
+        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(prm, lane4, (3 + f) * 256u));
+        mass = ldg<NT>(at<float>(prm, lane4, 10 * 256u));
     }
+}
+// The tile a wavefront works on, as a scalar: body i = block * BLOCK + thread with BLOCK a multiple of 64, so i >> 6 is
+// the same in all 64 lanes - told to the compiler with v_readfirstlane on the wave-in-block index.
+template <int BLOCK>
+__device__ __forceinline__ uint32_t wave_tile(uint32_t block)
+{
+    static_assert(BLOCK % 64 == 0, "one wavefront = one tile");
+    return block * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 }
 
 // The arguments are passed as individual scalars, the ones every wave needs before it can issue its first load in
@@ -488,29 +501,30 @@ __global__ void __launch_bounds__(BLOCK) HYDRO_TILED_OCC_ATTR wrench_tiled_kerne
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pv_out; a.pvo_stride = pvo_stride;
     a.prm = k_prm; a.out = k_out; a.out_stride = out_stride; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = warp; a.n = n;
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t tile = wave_tile<BLOCK>(blockIdx.x), lane = threadIdx.x & 63u;
+    const uint32_t first = tile * 64u;                              // (scalar) bodies of this tile that exist: all 64 but in the last one
+    // (scalar; written as n - min(n, first) through readfirstlane: as a saturating subtract the compiler moves it to the vector unit)
+    const uint32_t left = a.n - __builtin_amdgcn_readfirstlane(a.n < first ? a.n : first);
     if constexpr (!KE) {
-        if (i >= a.n) return;
+        if (lane >= left) return;
     }
     double ke_lin = 0.0, ke_rot = 0.0;
-    if (!KE || i < a.n) {                       // (KE: no early return - every thread reaches the block reduction)
-        const uint32_t tile = i >> 6, lane = i & 63u;
-        // tile < 2^24 and strides < 2^24 (checked on the host): full-rate 24-bit multiplies
-        const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
-        const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
+    if (!KE || lane < left) {                   // (KE: no early return - every thread reaches the block reduction)
+        // tile < 2^24 and strides < 2^24, byte offsets < 2^32 (checked on the host)
+        const uint32_t lane4 = lane * 4u;
         float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-        load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+        load_tile_records<HALF, NT>(a.st + (size_t)tile * a.st_stride, a.pv + (size_t)tile * a.pv_stride, a.prm, tile, lane4, s, pv, d, c, mass);
         const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, WARP);
         if constexpr (KE)
             hydro::kinetic_energy(s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], d[0], d[1], d[2], mass,
                                   ke_rotational != 0, ke_lin, ke_rot);
-        const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
-        stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
-        stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
+        float* out = a.out + (size_t)tile * a.out_stride;
+        stg<NT>(at<float>(out, lane4, 0u), w.fx); stg<NT>(at<float>(out, lane4, 256u), w.fy); stg<NT>(at<float>(out, lane4, 512u), w.fz);
+        stg<NT>(at<float>(out, lane4, 768u), w.tx); stg<NT>(at<float>(out, lane4, 1024u), w.ty); stg<NT>(at<float>(out, lane4, 1280u), w.tz);
         if constexpr (WRITE_PREV) {
-            const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
+            float* pvo = a.pv_out + (size_t)tile * a.pvo_stride;
 #pragma unroll
-            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo, f * 256u), s[7 + f]);
+            for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(pvo, lane4, f * 256u), s[7 + f]);
         }
     }
     if constexpr (KE) {
@@ -581,21 +595,18 @@ __global__ void __launch_bounds__(kBlock) HYDRO_TILED_OCC_ATTR wrench_tiled_batc
     TiledArgs a;
     a.st = b.st; a.st_stride = b.st_stride; a.pv = b.pv; a.pv_stride = b.pv_stride; a.pv_out = b.pv_out; a.pvo_stride = b.pvo_stride;
     a.prm = b.prm; a.out = b.out; a.out_stride = b.out_stride; a.rho = b.rho; a.g = b.g; a.inv_dt = args.inv_dt; a.warp = WARP; a.n = b.n;
-    const uint32_t i = (bid - first) * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    const uint32_t tile = i >> 6, lane = i & 63u;
-    const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
-    const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
+    const uint32_t tile = wave_tile<kBlock>(bid - first), lane = threadIdx.x & 63u, lane4 = lane * 4u;     // (wave-uniform, see load_tile_records)
+    if (tile * 64u + lane >= a.n) return;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-    load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+    load_tile_records<HALF, NT>(a.st + (size_t)tile * a.st_stride, a.pv + (size_t)tile * a.pv_stride, a.prm, tile, lane4, s, pv, d, c, mass);
     const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, WARP);
-    const uint32_t oo = (__umul24(tile, a.out_stride) + lane) * 4u;
-    stg<NT>(at<float>(a.out, oo), w.fx); stg<NT>(at<float>(a.out, oo, 256u), w.fy); stg<NT>(at<float>(a.out, oo, 512u), w.fz);
-    stg<NT>(at<float>(a.out, oo, 768u), w.tx); stg<NT>(at<float>(a.out, oo, 1024u), w.ty); stg<NT>(at<float>(a.out, oo, 1280u), w.tz);
+    float* out = a.out + (size_t)tile * a.out_stride;
+    stg<NT>(at<float>(out, lane4, 0u), w.fx); stg<NT>(at<float>(out, lane4, 256u), w.fy); stg<NT>(at<float>(out, lane4, 512u), w.fz);
+    stg<NT>(at<float>(out, lane4, 768u), w.tx); stg<NT>(at<float>(out, lane4, 1024u), w.ty); stg<NT>(at<float>(out, lane4, 1280u), w.tz);
     if constexpr (WRITE_PREV) {
-        const uint32_t wo = (__umul24(tile, a.pvo_stride) + lane) * 4u;
+        float* pvo = a.pv_out + (size_t)tile * a.pvo_stride;
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(a.pv_out, wo, f * 256u), s[7 + f]);
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(pvo, lane4, f * 256u), s[7 + f]);
     }
 }
 
@@ -772,9 +783,11 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
                                                                   float* k_pv, const float* k_prm, int quat_xyzw, uint32_t n,      // 16 dwords: preloaded
                                                                   int warp, double rho, double g, double inv_dt)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t tile = i >> 6, lane = i & 63u;
+    // (wave-uniform tile: the bases of the tile's rows and records are scalar adds, see load_tile_records)
+    const uint32_t tile = wave_tile<kBlock>(blockIdx.x), lane = threadIdx.x & 63u, lane4 = lane * 4u;
+    if (tile * 64u + lane >= n) return;
+    const size_t first = (size_t)tile * 64u;
+    const float* t_pos = k_pos + first * 3; const float* t_quat = k_quat + first * 4; const float* t_vel = k_vel + first * 6;
     float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
     // The simulator's rows are read with TEMPORAL loads whatever the size: the simulator has just written them, so they
     // are the one input that can still be in L2 / the Infinity Cache (the engine's own records and the outputs stream).
@@ -782,40 +795,40 @@ __global__ void __launch_bounds__(kBlock) wrench_aos_direct_kernel(const float* 
     // of 1 M bodies: 29.84 vs 29.96 us; 4 M: 112.2 vs 112.3), 12 % faster when the rows are (4 sets: 26.5 vs 30.2 us) -
     // which is also why bench.py rotates EIGHT sets for this entry: its figure must be an HBM rate.
     constexpr bool RNT = false;
-    const f3_a4 p = ld_f3_a4<RNT>(k_pos, i * 12u);
-    const f4_a16 q = ld_f4_a16<RNT>(k_quat, i * 16u);
-    const f4_a8 v0 = ld_f4_a8<RNT>(k_vel, i * 24u);
-    const f2_a8 v1 = ld_f2_a8<RNT>(k_vel, i * 24u + 16u);
+    const f3_a4 p = ld_f3_a4<RNT>(t_pos, lane * 12u);
+    const f4_a16 q = ld_f4_a16<RNT>(t_quat, lane * 16u);
+    const f4_a8 v0 = ld_f4_a8<RNT>(t_vel, lane * 24u);
+    const f2_a8 v1 = ld_f2_a8<RNT>(t_vel, lane * 24u + 16u);
     s[0] = p.x; s[1] = p.y; s[2] = p.z;
     if (quat_xyzw) { s[3] = q.x; s[4] = q.y; s[5] = q.z; s[6] = q.w; }
     else           { s[3] = q.y; s[4] = q.z; s[5] = q.w; s[6] = q.x; }   // wxyz -> xyzw (hydrodynamics_behavior.py:194)
     s[7] = v0.x; s[8] = v0.y; s[9] = v0.z; s[10] = v0.w; s[11] = v1.x; s[12] = v1.y;
-    const uint32_t po = (__umul24(tile, HYDRO_PREV_FIELDS * HYDRO_TILE) + lane) * 4u;
+    float* t_pv = k_pv + (size_t)tile * (HYDRO_PREV_FIELDS * HYDRO_TILE);
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(k_pv, po, f * 256u));
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) pv[f] = ldg<NT>(at<float>(t_pv, lane4, f * 256u));
     if constexpr (HALF) {
-        const uint32_t qo = __umul24(tile, kPrmTileF16 * 4u) + lane * 4u;
+        const float* prm = k_prm + (size_t)tile * kPrmTileF16;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(k_prm, qo, f * 256u));
-        mass = ldg<NT>(at<float>(k_prm, qo, 3 * 256u));
-        const uint32_t ho = __umul24(tile, kPrmTileF16 * 4u) + 1024u + lane * 2u;
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(prm, lane4, f * 256u));
+        mass = ldg<NT>(at<float>(prm, lane4, 3 * 256u));
+        const uint32_t lane2 = lane4 >> 1;
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(k_prm, ho, f * 128u)));
+        for (int f = 0; f < 7; ++f) c[f] = half_bits_to_float(ldg<NT>(at<unsigned short>(prm, lane2, 1024u + f * 128u)));
     } else {
-        const uint32_t qo = __umul24(tile, kPrmTileF32 * 4u) + lane * 4u;
+        const float* prm = k_prm + (size_t)tile * kPrmTileF32;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(k_prm, qo, f * 256u));
+        for (int f = 0; f < 3; ++f) d[f] = ldg<NT>(at<float>(prm, lane4, f * 256u));
 #pragma unroll
-        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(k_prm, qo + (3 + f) * 256u));
-        mass = ldg<NT>(at<float>(k_prm, qo, 10 * 256u));
+        for (int f = 0; f < 7; ++f) c[f] = ldg<NT>(at<float>(prm, lane4, (3 + f) * 256u));
+        mass = ldg<NT>(at<float>(prm, lane4, 10 * 256u));
     }
     const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, WARP);
 #pragma unroll
-    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg_aos<NT>(at<float>(k_pv, po, f * 256u), s[7 + f]);
+    for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg_aos<NT>(at<float>(t_pv, lane4, f * 256u), s[7 + f]);
     f3_a4 fo, to;
     fo.x = w.fx; fo.y = w.fy; fo.z = w.fz; to.x = w.tx; to.y = w.ty; to.z = w.tz;
-    st_f3_a4<NT>(k_force, i * 12u, fo);
-    st_f3_a4<NT>(k_torque, i * 12u, to);
+    st_f3_a4<NT>(k_force + first * 3, lane * 12u, fo);
+    st_f3_a4<NT>(k_torque + first * 3, lane * 12u, to);
 }
 
 // --------------------------------------------------------------------------
@@ -1092,17 +1105,15 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k
     fa.t.prm = k_prm; fa.t.out = k_out; fa.t.out_stride = out_stride; fa.t.rho = rho; fa.t.g = g; fa.t.inv_dt = inv_dt; fa.t.warp = warp; fa.t.n = n;
     fa.so = k_so; fa.so_stride = so_stride; fa.dt = dt;
     const TiledArgs& a = fa.t;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t tile = wave_tile<kBlock>(blockIdx.x), lane = threadIdx.x & 63u, lane4 = lane * 4u;      // (wave-uniform, see load_tile_records)
+    const bool live = tile * 64u + lane < a.n;
     if constexpr (!KE) {
-        if (i >= a.n) return;
+        if (!live) return;
     }
     double ke_lin = 0.0, ke_rot = 0.0;
-    if (!KE || i < a.n) {
-        const uint32_t tile = i >> 6, lane = i & 63u;
-        const uint32_t so = (__umul24(tile, a.st_stride) + lane) * 4u;
-        const uint32_t po = (__umul24(tile, a.pv_stride) + lane) * 4u;
+    if (!KE || live) {
         float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-        load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+        load_tile_records<HALF, NT>(a.st + (size_t)tile * a.st_stride, a.pv + (size_t)tile * a.pv_stride, a.prm, tile, lane4, s, pv, d, c, mass);
         const hydro::Wrench w = body_wrench(s, pv, d, c, mass, a.rho, a.g, a.inv_dt, WARP);
         const float k_lin = w.k_lin, k_ang = w.k_ang;     // used by the implicit form only
         const float f6[HYDRO_WRENCH_FIELDS] = {w.fx, w.fy, w.fz, w.tx, w.ty, w.tz};
@@ -1111,13 +1122,13 @@ __global__ void __launch_bounds__(kBlock) step_fused_tiled_kernel(const float* k
         if constexpr (KE)
             hydro::kinetic_energy(o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], d[0], d[1], d[2], mass,
                                   ke_rotational != 0, ke_lin, ke_rot);
-        const uint32_t oo = (__umul24(tile, fa.so_stride) + lane) * 4u;
+        float* so = fa.so + (size_t)tile * fa.so_stride;
 #pragma unroll
-        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(fa.so, oo, f * 256u), o[f]);
+        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(so, lane4, f * 256u), o[f]);
         if (a.out) {
-            const uint32_t wo = (__umul24(tile, a.out_stride) + lane) * 4u;
+            float* wout = a.out + (size_t)tile * a.out_stride;
 #pragma unroll
-            for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(a.out, wo, f * 256u), f6[f]);
+            for (int f = 0; f < HYDRO_WRENCH_FIELDS; ++f) stg<NT>(at<float>(wout, lane4, f * 256u), f6[f]);
         }
     }
     if constexpr (KE) ke_block_reduce(ke_lin, ke_rot, ke_partials, ke_stride, ke_out);
@@ -1141,17 +1152,15 @@ __global__ void __launch_bounds__(kBlock) step_fused_multi_tiled_kernel(const fl
     TiledArgs a;
     a.st = k_st; a.st_stride = st_stride; a.pv = k_pv; a.pv_stride = pv_stride; a.pv_out = k_pvo; a.pvo_stride = pvo_stride;
     a.prm = k_prm; a.out = nullptr; a.out_stride = 0; a.rho = rho; a.g = g; a.inv_dt = inv_dt; a.warp = WARP; a.n = n;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t tile = wave_tile<kBlock>(blockIdx.x), lane = threadIdx.x & 63u, lane4 = lane * 4u;      // (wave-uniform, see load_tile_records)
+    const bool live = tile * 64u + lane < n;
     if constexpr (!KE) {
-        if (i >= n) return;
+        if (!live) return;
     }
     double ke_lin = 0.0, ke_rot = 0.0;
-    if (!KE || i < n) {
-        const uint32_t tile = i >> 6, lane = i & 63u;
-        const uint32_t so = (__umul24(tile, st_stride) + lane) * 4u;
-        const uint32_t po = (__umul24(tile, pv_stride) + lane) * 4u;
+    if (!KE || live) {
         float s[HYDRO_STATE_FIELDS], pv[HYDRO_PREV_FIELDS], d[3], c[7], mass;
-        load_tile_records<HALF, NT>(a, tile, lane, so, po, s, pv, d, c, mass);
+        load_tile_records<HALF, NT>(k_st + (size_t)tile * st_stride, k_pv + (size_t)tile * pv_stride, k_prm, tile, lane4, s, pv, d, c, mass);
 #pragma unroll 1
         for (uint32_t k = 0; k < steps; ++k) {
             const hydro::Wrench w = body_wrench(s, pv, d, c, mass, rho, g, inv_dt, WARP);
@@ -1166,12 +1175,12 @@ __global__ void __launch_bounds__(kBlock) step_fused_multi_tiled_kernel(const fl
         if constexpr (KE)
             hydro::kinetic_energy(s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], d[0], d[1], d[2], mass,
                                   ke_rotational != 0, ke_lin, ke_rot);
-        const uint32_t wo = (__umul24(tile, pvo_stride) + lane) * 4u;
+        float* pvo = k_pvo + (size_t)tile * pvo_stride;
 #pragma unroll
-        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(k_pvo, wo, f * 256u), pv[f]);
-        const uint32_t oo = (__umul24(tile, so_stride) + lane) * 4u;
+        for (int f = 0; f < HYDRO_PREV_FIELDS; ++f) stg<NT>(at<float>(pvo, lane4, f * 256u), pv[f]);
+        float* so = k_so + (size_t)tile * so_stride;
 #pragma unroll
-        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(k_so, oo, f * 256u), s[f]);
+        for (int f = 0; f < HYDRO_STATE_FIELDS; ++f) stg<NT>(at<float>(so, lane4, f * 256u), s[f]);
     }
     if constexpr (KE) ke_block_reduce(ke_lin, ke_rot, ke_partials, ke_stride, ke_out);
 }

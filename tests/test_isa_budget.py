@@ -66,11 +66,15 @@ def test_headline_kernel_is_what_the_measurements_describe(assembly):
     assert len(stores) == 6 and all(l.rstrip().endswith("sc0 sc1") for l in stores)       # write-through, not nt
     assert not any(i.startswith(("ds_", "scratch_", "buffer_")) for i in ins)
     valu = [i for i in ins if i.startswith("v_")]
-    assert len(valu) <= 465, len(valu)                         # round 2: 520; after the round-3 diet: 460
+    assert len(valu) <= 446, len(valu)                         # round 2: 520; round-3 diet: 462; round 6 (scalar tile addressing, bit flags): 444
     fp64 = [i for i in valu if i.endswith("_f64") or "_f64_" in i]
     assert len(fp64) <= 340
-    # every field offset sits in the instruction's immediate: one address register per record, no 64-bit address arithmetic
-    assert sum(i.startswith(("v_lshl_add_u64", "v_add_co", "v_addc_co")) for i in valu) == 0
+    # The tile index is wave-uniform (round 6): record bases are SCALAR adds, every field offset an instruction immediate, and
+    # the per-lane addressing of a body is lane * 4, lane * 2 and ONE 64-bit add for the six write-through stores (atomic
+    # stores take no scalar base) - no 24-bit multiplies, no add-shifts per record
+    addressing = [i for i in valu if i.startswith(("v_lshl_add_u64", "v_add_co", "v_addc_co", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_lshl", "v_lshl_or"))]
+    assert addressing == ["v_lshl_add_u64"], addressing
+    assert sum(i == "v_readfirstlane_b32" for i in valu) == 1 and "s_mul_i32" in ins
 
 
 def test_array_of_structs_kernel_keeps_nt_stores_and_row_accesses(assembly):
