@@ -350,7 +350,7 @@ def load_traffic(workload: str):
 
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "config", "roofline", "cpu_baseline")
-def _round(x, sig: int = 9):
+def _round(x, sig: int = 12):
     """Numbers as short as they are meaningful: floats to `sig` significant digits, recursively; everything else untouched."""
     if isinstance(x, float):
         return float(f"{x:.{sig}g}") if math.isfinite(x) else None
@@ -362,7 +362,7 @@ def _round(x, sig: int = 9):
 
 
 def render_line(out: dict) -> str:
-    """The JSON line for `out`: compact separators, floats to 9 significant digits (`value` and `ms_per_step` in full), and at
+    """The JSON line for `out`: compact separators, floats to 12 significant digits (`value` and `ms_per_step` in full), and at
     most LINE_LIMIT bytes BY CONSTRUCTION: should a line ever exceed it (this file's own blocks fit twice over), whole
     non-contract blocks are dropped, the largest first, and named in `dropped_for_size`; the contract keys always stay."""
     keep_full = {k: out[k] for k in ("value", "ms_per_step") if k in out}

@@ -131,7 +131,7 @@ def test_bench_two_ranks_share_the_gpu(native_built):
     sc = scenes.scene_c4(n=262144, seed=4)
     m = sc.params[:, 10].astype(np.float64)
     lin = float((0.5 * m * (sc.state[:, 7:10].astype(np.float64) ** 2).sum(1)).sum())
-    assert ke["host_fp64_J"][0] == pytest.approx(lin, rel=1e-13) and ke["global_J"][0] == pytest.approx(lin, rel=1e-12)
+    assert ke["host_fp64_J"][0] == pytest.approx(lin, rel=1e-11) and ke["global_J"][0] == pytest.approx(lin, rel=1e-11)      # (12 digits on the line)
 
 
 def test_bench_two_ranks_long_region_keeps_the_256_step_cadence(native_built):

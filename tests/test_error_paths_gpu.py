@@ -2,6 +2,7 @@
 must come back as HYDRO_E_ARG with a message in hydro_last_error, launch nothing, and leave the engine usable.
 Called through the raw C ABI (ctypes), the way a foreign host would."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
