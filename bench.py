@@ -599,7 +599,7 @@ def main():
 
     # N > 1: BASELINE configs[3] as stated (262 144 bodies over the N GPUs) on every rank.  The headline is complete at this
     # point; whatever happens to this leg, rank 0 still prints it (LegGuard) - and the exit code says so.
-    strong = None
+    strong, guard = None, None
     if multi and not args.no_strong_leg:
         from scripts import bench_strong
         guard = bench_strong.LegGuard(rank, out, json_fd, float(os.environ.get("HYDRO_BENCH_STRONG_TIMEOUT", bench_strong.STRONG_LEG_TIMEOUT_S)))
@@ -658,15 +658,22 @@ def main():
             out["extras_file"] = os.path.basename(write_side_file(args.extras_out, side) or "") or None
         sys.stdout.flush()
         write_all(json_fd, (render_line(out) + "\n").encode())
+        if guard is not None:
+            guard.line_is_out()
 
-    # (the line is out) a rank that never arrives here must not look like a pass: the teardown barrier has a deadline
+    # (the line is out) a rank that never arrives here must not look like a pass: the teardown barrier has a deadline, and a
+    # rank that gives up on it leaves THROUGH the guard (rank 0's line first, then exit code 3 everywhere)
     try:
         hd.barrier(timeout_s=float(os.environ.get("HYDRO_BENCH_TEARDOWN_TIMEOUT", "60")))
+        if guard is not None:
+            guard.finish()
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
     except Exception as e:                                  # noqa: BLE001
         sys.stderr.write(f"bench.py: rank {rank}: teardown: {e!r}\n")
         sys.stderr.flush()
+        if guard is not None:
+            guard.leave(f"teardown: {e!r} on rank {rank}; the headline on this line is complete")
         os._exit(EXIT_LEG_FAILED)
 
 

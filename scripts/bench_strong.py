@@ -219,16 +219,21 @@ STRONG_LEG_TIMEOUT_S = 240.0
 
 
 class LegGuard:
-    """Keeps the headline safe from the N > 1 leg, and the exit code honest.  The leg is the one part of this file no hardware
-    with more than one GPU has run; it sits after the headline measurement.  If a rank raises in it, or a collective in it never
-    returns, rank 0 still prints the line it has - with "ok": false and `c4_strong.error` - and THEN every rank leaves with
-    exit code 3 (os._exit: the main thread may be blocked inside a collective, where no Python exception or signal handler
-    runs; a process that holds the GPU is never re-exec'ed).  The order matters under torchrun, which tears the job down as
-    soon as one rank has failed: a failing rank k > 0 first drops a marker file and waits (bounded) for rank 0's "line is
-    out" marker; every rank's watchdog thread polls for markers, so rank 0 reacts within a quarter of a second."""
+    """Keeps the headline safe from the N > 1 leg, and the exit code honest.  The leg is the one part of the bench no hardware
+    with more than one GPU has run; it sits after the headline measurement.  If a rank raises in it, or a collective in it (or
+    the teardown barrier after it) never returns, rank 0 still prints the line it has - with "ok": false and `c4_strong.error` -
+    and THEN every rank leaves with exit code 3 (os._exit: the main thread may be blocked inside a collective, where no Python
+    exception or signal handler runs; a process that holds the GPU is never re-exec'ed, nothing is retried).
+    The ORDER matters under torchrun, which tears the job down as soon as one rank has failed: a failing rank k > 0 first drops
+    a marker file and waits (bounded) until rank 0 has its line out; every rank's watchdog thread polls for markers four times
+    a second, so rank 0 reacts at once.  Marker files (temp dir, name drawn by rank 0 and broadcast before the leg):
+    <base>.fault.<k> = rank k is leaving, with the reason; <base>.out = rank 0's line is on stdout (a complete one or a
+    failure one); <base>.failed = rank 0 has left with a failure.  The guard stays armed until the teardown barrier is behind
+    every rank (finish()): a rank that waits there for one that hangs must not leave before rank 0 has printed."""
 
     def __init__(self, rank: int, headline: dict | None, json_fd: int, timeout_s: float):
         import tempfile
+        import threading
         self.rank, self.headline, self.fd, self.timeout_s = rank, headline, json_fd, timeout_s
         name = [f"hydro_bench_{os.getuid()}_{os.urandom(8).hex()}" if rank == 0 else None]
         if hd._collectives_on():                            # (a collective - but the headline's own collectives have just worked)
@@ -237,40 +242,61 @@ class LegGuard:
         self.progress: dict = {}
         self.extra: dict = {}                               # fields rank 0 already has for the line (cpu_baseline)
         self._done = False
-        import threading
+        self._deadline = time.monotonic() + timeout_s
         self._lock = threading.Lock()
         self._thread = threading.Thread(target=self._watch, daemon=True)
         self._thread.start()
 
-    def _faults(self):
-        import glob
-        return sorted(glob.glob(self.base + ".fault.*"))
+    def _touch(self, suffix: str, text: str = "") -> None:
+        try:
+            with open(self.base + suffix, "w") as f:
+                f.write(text)
+        except OSError:
+            pass
 
     def _watch(self):
-        t_end = time.monotonic() + self.timeout_s
+        import glob
         while not self._done:
-            hits = self._faults()
+            if self.rank != 0 and os.path.exists(self.base + ".failed"):
+                os._exit(EXIT_LEG_FAILED)                   # rank 0 has printed its failure line and left
+            hits = sorted(glob.glob(self.base + ".fault.*"))
             if hits:
                 try:
-                    why = open(hits[0]).read().strip()
+                    why = open(hits[0]).read().strip() or "a rank failed"
                 except OSError:
                     why = "a rank failed"
                 self.leave(why, mark=False)
-            if time.monotonic() > t_end:
+            if time.monotonic() > self._deadline:
                 self.leave(f"no result after {self.timeout_s:.0f} s (a rank raised or a collective did not return); the headline on this line is complete")
             time.sleep(0.25)
 
-    def finish(self):
+    def leg_done(self, allowance_s: float = 180.0) -> None:
+        """The leg returned on this rank: what is left is rank 0's line and the teardown barrier - a fresh deadline for those."""
+        self._deadline = time.monotonic() + allowance_s
+
+    def line_is_out(self) -> None:
+        """Rank 0 has written its (complete) line: nothing is ever printed again, and nobody needs to wait for it."""
+        self.headline = None
+        self._touch(".out")
+
+    def finish(self) -> None:
+        """Every rank is through the teardown barrier: disarm; rank 0 removes the markers."""
         self._done = True
+        if self.rank == 0:
+            for suffix in (".out",):
+                try:
+                    os.unlink(self.base + suffix)
+                except OSError:
+                    pass
 
     def leave(self, why: str, mark: bool = True):
         with self._lock:                                    # (watchdog thread and main thread: only one of them leaves)
-            if self._done and mark is False:
+            if self._done:
                 return
             sys.stderr.write(f"bench.py: rank {self.rank}: configs[3] leg: {why}\n")
             sys.stderr.flush()
             if self.rank == 0:
-                if self.headline is not None:
+                if self.headline is not None:               # (None: the complete line is out already - the failure is the exit code)
                     if "main" in self.progress:             # the host-driven leg had finished: only the captured variant is lost
                         strong = dict(self.progress["main"], captured={"error": why})
                     else:
@@ -278,17 +304,11 @@ class LegGuard:
                     line = dict(self.headline, cpu_baseline=None)
                     line.update(self.extra, c4_strong=strong, ok=False)
                     write_all(self.fd, (render_line(line) + "\n").encode())
-                try:
-                    open(self.base + ".out", "w").close()
-                except OSError:
-                    pass
+                self._touch(".out")
+                self._touch(".failed")
             else:
                 if mark:
-                    try:
-                        with open(f"{self.base}.fault.{self.rank}", "w") as f:
-                            f.write(why)
-                    except OSError:
-                        pass
+                    self._touch(f".fault.{self.rank}", why)
                 t_end = time.monotonic() + 20.0             # rank 0 prints first (torchrun ends the job at the first failed rank)
                 while not os.path.exists(self.base + ".out") and time.monotonic() < t_end:
                     time.sleep(0.05)
@@ -306,7 +326,7 @@ def guarded_strong_leg(rank: int, world: int, dev, stream, args, multi: bool, gu
         if fault == f"hang-resident:{rank}":
             globals()["strong_leg_graph_resident"] = lambda *a, **k: time.sleep(3600)
         res = c4_strong_leg(rank, world, dev, stream, args.steps, args.warmup, collectives=multi, progress=guard.progress)
-        guard.finish()
+        guard.leg_done()
         return res
     except Exception as e:                                  # noqa: BLE001 - the other ranks may be inside a collective: leave, do not wait
         guard.leave(f"{e!r} on rank {rank}; the headline on this line is complete")

@@ -227,13 +227,13 @@ def test_bench_four_ranks_share_the_gpu(native_built):
     assert cs["ke"]["rel_err"] <= 1e-12 and cs["shards_bit_identical"] is True
 
 
-def _faulty_run(fault, via_torchrun=True):
+def _faulty_run(fault, via_torchrun=True, strong_timeout="8", teardown_timeout="10"):
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HYDRO_BENCH_SHARE_GPU="1", HYDRO_DIST_BACKEND="gloo", HYDRO_BENCH_STRONG_FAULT=fault, HYDRO_BENCH_STRONG_TIMEOUT="8",
-               HYDRO_BENCH_TEARDOWN_TIMEOUT="10")
+    env.update(HYDRO_BENCH_SHARE_GPU="1", HYDRO_DIST_BACKEND="gloo", HYDRO_BENCH_STRONG_FAULT=fault, HYDRO_BENCH_STRONG_TIMEOUT=strong_timeout,
+               HYDRO_BENCH_TEARDOWN_TIMEOUT=teardown_timeout)
     tail = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--bodies", "65536", "--spinup-seconds", "0.1"]
     if via_torchrun:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -275,3 +275,20 @@ def test_self_launch_relays_the_line_and_exit_code_3(native_built):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["ok"] is False and d["n_gpus"] == 2 and d["value"] > 1e8 and "error" in d["c4_strong"]
+
+
+def test_a_rank_that_gives_up_at_the_teardown_barrier_lets_rank_0_print_first(native_built):
+    """The production ordering of the deadlines: the teardown barrier (60 s) is SHORTER than the leg's watchdog (240 s).  Rank 0 hangs
+    in the captured variant; rank 1 is through its leg and gives up on the teardown barrier long before rank 0's watchdog would
+    fire.  It must not simply exit (torchrun would end the job and the headline with it): it leaves through the guard - marker,
+    wait for rank 0's line - and rank 0, polling for markers, prints at once.  Here: watchdog 90 s, teardown 5 s, done well under 60 s."""
+    import time
+    t0 = time.monotonic()
+    res = _faulty_run("hang-resident:0", strong_timeout="90", teardown_timeout="5")
+    took = time.monotonic() - t0
+    assert res.returncode != 0 and took < 75, (took, res.stderr[-2000:])
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["ok"] is False and d["value"] > 1e8 and d["c4_strong"]["shards_bit_identical"] is True
+    assert "teardown" in d["c4_strong"]["captured"]["error"] and "node barrier" in d["c4_strong"]["captured"]["error"]
