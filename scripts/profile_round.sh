@@ -11,7 +11,7 @@ rm -rf "$out"; mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 python3 bench.py --extras-out "$out/bench_extras.json" > "$out/bench.json" 2> "$out/bench.err" || exit 1
-# which kind of box this is, FIRST: a box that throttles under the combined load (kernel_over_memory_only >= 1.2) reads 0.65-0.75
+# which kind of box this is, FIRST: a box that throttles under the combined load (kernel_over_memory_only >= 1.15; ordinary boxes read 1.03-1.06) reads 0.65-0.75
 # of the HBM peak where an ordinary one reads 0.77-0.81; collect_profiles.py puts it in the tag's README row
 python3 -c "import json,sys; d=json.load(open('$out/bench.json')); b=d.get('box') or {}; print('[box] kernel_over_memory_only', b.get('kernel_over_memory_only'), 'clock_held_ghz', b.get('clock_held_ghz'), 'throttles', b.get('throttles_under_combined_load'), '| frac', d['roofline']['frac'], 'line bytes', len(open('$out/bench.json').read()))"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --cpu-seconds 0 --no-extras --no-configs --no-roofline-4m --no-live-traffic > "$out/bench_stats.json" 2> "$out/stats.err" || exit 1

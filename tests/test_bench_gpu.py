@@ -75,7 +75,7 @@ def test_default_run_writes_the_side_file_and_a_short_line(native_built, tmp_pat
     assert "frac_median_of_5" in d["roofline"] and d["extras_file"] == "extras.json" and "extras" not in d
     box = d["box"]                                               # which kind of box this is, on the line
     assert box["kernel_over_memory_only"] == pytest.approx(box["kernel_us"] / box["memory_only_us"], rel=1e-6)
-    assert 1.0 < box["clock_held_ghz"] < 3.0 and box["throttles_under_combined_load"] == (box["kernel_over_memory_only"] >= 1.2)
+    assert 1.0 < box["clock_held_ghz"] < 3.0 and box["throttles_under_combined_load"] == (box["kernel_over_memory_only"] >= 1.15)
     payload = json.loads(side.read_text())
     assert payload["line"]["value"] == d["value"] and "bound_probes_1m" in payload["extras"] and "clocks_1m" in payload["extras"]
     assert "bench.py: side file (extras):" in res.stderr
