@@ -1555,8 +1555,12 @@ int ke_prepare(hydro_engine* h, hipStream_t s)
             if (!h->ke_event && hipEventCreateWithFlags(&h->ke_event, hipEventDisableTiming) != hipSuccess) h->ke_event = nullptr;
             // (the previous stream may be gone: a failed record means there is nothing left to wait for - its error, and only
             // its error, is dropped here; an error the caller's own code left pending is not this function's to swallow)
-            if (h->ke_event && hipEventRecord(h->ke_event, h->ke_last_stream) == hipSuccess)
-                HYDRO_HIP(h, hipStreamWaitEvent(s, h->ke_event, 0), HYDRO_E_LAUNCH);
+            if (h->ke_event) {
+                if (hipEventRecord(h->ke_event, h->ke_last_stream) == hipSuccess)
+                    HYDRO_HIP(h, hipStreamWaitEvent(s, h->ke_event, 0), HYDRO_E_LAUNCH);
+                else
+                    (void)hipGetLastError();   // the record's own error only (the launch checks that follow must not trip over it)
+            }
         }
     }
     // (2) re-arm after a fault seen on this handle.  Not while `s` is being captured: a memset recorded into a graph runs

@@ -127,3 +127,21 @@ def test_write_all_loops_over_short_writes(monkeypatch):
 def test_explain_prints_the_field_notes():
     res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--explain"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "roofline.frac" in res.stdout and "kernel_over_memory_only" in res.stdout
+
+
+def test_box_summary_from_canned_probes():
+    """`box` on the line (scripts/bench_extras.box_summary): which bound binds on this box, the clock it holds, and the flag -
+    ordinary boxes read 1.03-1.06, boxes that throttle under the combined load 1.20-1.32; the line between them is 1.15."""
+    import sys
+    sys.path.insert(0, REPO)
+    from scripts import bench_extras as be
+    probes = {"memory_only_us": 20.5, "compute_only_us": 16.1, "kernel_us": 21.4, "kernel_over_memory_only": 21.4 / 20.5, "binding": "hbm"}
+    clocks = {"whole_body_ghz": 2.09, "memory_only_ghz": 2.37, "compute_only_ghz": 2.56}
+    box = be.box_summary({"bound_probes_1m": probes, "clocks_1m": clocks})
+    assert box["throttles_under_combined_load"] is False and box["clock_held_ghz"] == 2.09 and box["binding"] == "hbm"
+    slow = dict(probes, kernel_us=24.53, kernel_over_memory_only=24.53 / 20.46)
+    assert be.box_summary({"bound_probes_1m": slow, "clocks_1m": clocks})["throttles_under_combined_load"] is True
+    assert be.box_summary({"bound_probes_1m": {"error": "x"}}) is None and be.box_summary({}) is None
+    only_probes = be.box_summary({"bound_probes_1m": probes, "clocks_1m": {"skipped": "extras time budget"}})
+    assert "clock_held_ghz" not in only_probes and only_probes["kernel_us"] == 21.4
+    assert be.THROTTLE_RATIO == 1.15 and "kernel_over_memory_only >= 1.15" in be.FIELD_NOTES
