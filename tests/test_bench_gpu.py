@@ -292,3 +292,17 @@ def test_a_rank_that_gives_up_at_the_teardown_barrier_lets_rank_0_print_first(na
     d = json.loads(lines[0])
     assert d["ok"] is False and d["value"] > 1e8 and d["c4_strong"]["shards_bit_identical"] is True
     assert "teardown" in d["c4_strong"]["captured"]["error"] and "node barrier" in d["c4_strong"]["captured"]["error"]
+
+
+def test_bench_through_the_array_of_structs_entry(native_built):
+    """`--layout aos` (what scripts/profile_aos.sh profiles): the simulator-facing entry as the bench workload - 168 algorithmic bytes
+    per body-step, all of them real traffic, eight or more rotating sets so that no rows stay in the Infinity Cache."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--layout", "aos", "--workload", "c5-f32",
+           "--bodies", "65536", "--cpu-seconds", "1", "--no-extras", "--no-configs"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    assert d["config"]["entry_point"] == "hydro_step_wrench_aos" and d["config"]["bytes_per_body_step"] == 168
+    assert d["roofline"]["kernel"] == "wrench_aos_direct_kernel" and d["roofline"]["traffic_bytes_per_body"] == 168
+    assert d["config"]["scene_replicas_per_gpu"] * 65536 * 52 >= (410 << 20) and "configs" not in d
+    assert d["cpu_baseline"]["gpu_vs_oracle_max_rel_err"] <= 1e-5 and d["max_rel_err"] <= 1e-5      # the CPU leg checks this entry's result too
