@@ -222,7 +222,7 @@ def cpu_baseline_leg(sc, replica, budget_s: float):
     m = min(sc.n, 262144)
     idx = replica.index[:m]
     st, pv, pr = sc.state[idx], sc.prev[idx], sc.params[idx]
-    if replica.layout == "aos":          # this entry keeps the previous velocity IN THE ENGINE and updates it every step: the state
+    if replica.layout == "aos" or os.environ.get("HYDRO_BENCH_OWN_PREV") == "1":     # this entry keeps the previous velocity IN THE ENGINE and updates it every step: the state
         pv = np.ascontiguousarray(st[:, 7:13])      # does not change between the bench's steps, so from the second step on it equals the velocity
     c_oracle.wrench(st[:1024], pv[:1024], pr[:1024], sc.rho, sc.g, sc.dt)          # warm
     reps, t0 = 0, time.perf_counter()
