@@ -306,3 +306,29 @@ def test_bench_through_the_array_of_structs_entry(native_built):
     assert d["roofline"]["kernel"] == "wrench_aos_direct_kernel" and d["roofline"]["traffic_bytes_per_body"] == 168
     assert d["config"]["scene_replicas_per_gpu"] * 65536 * 52 >= (410 << 20) and "configs" not in d
     assert d["cpu_baseline"]["gpu_vs_oracle_max_rel_err"] <= 1e-5 and d["max_rel_err"] <= 1e-5      # the CPU leg checks this entry's result too
+
+
+@pytest.mark.parametrize("flags,entry,n", [
+    (["--workload", "c2"], "hydro_step_wrench_tiled", 4096),
+    (["--workload", "c3"], "hydro_step_wrench_tiled", 19456),
+    (["--workload", "c4", "--layout", "soa"], "hydro_step_wrench_ext", 262144),
+    (["--workload", "c5-f32", "--bodies", "100001"], "hydro_step_wrench_tiled", 100001),          # a ragged last tile
+])
+def test_bench_other_workloads_and_layouts(native_built, flags, entry, n):
+    """Every workload / layout the bench offers still produces a checked line (the CPU leg is the checker: gate 1e-5)."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0.5",
+           "--no-extras", "--no-configs", "--spinup-seconds", "0.1"] + flags
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    assert d["config"]["entry_point"] == entry and d["config"]["bodies_per_gpu"] == n and d["ok"] is True
+    assert d["cpu_baseline"]["gpu_vs_oracle_n_over_1e-5"] == 0 and d["max_rel_err"] <= 1e-5
+    assert d["collective"]["ke_rel_err"] <= 1e-12 and d["value"] == pytest.approx(n / (d["ms_per_step"] * 1e-3), rel=1e-9)
+
+
+def test_bench_strong_scaling_flag_two_ranks(native_built):
+    """`--scaling strong`: the workload's bodies block-partitioned over the ranks (two, sharing the GPU over gloo)."""
+    d = _two_rank_run(20, 5, extra=("--scaling", "strong", "--no-strong-leg"))
+    assert d["scaling"] == "strong" and d["config"]["bodies_per_gpu"] == 32768 and "strong scaling: 65536 bodies over 2 GPUs" in d["config"]["workload"]
+    assert d["value"] == pytest.approx(65536 / (d["ms_per_step"] * 1e-3), rel=1e-6) and "c4_strong" not in d
+    assert d["collective"]["ke_rel_err"] <= 1e-12
